@@ -1,0 +1,152 @@
+/*
+ * openclip_hip.h -- C ABI of libopenclip_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * CLIP training hot path of mlfoundations/open_clip.
+ *
+ * The reference has no native code: its device work is a set of ATen / c10d call sites
+ * (SURVEY.md 2.3, K1..K14).  Every entry point below names the reference call site it replaces
+ * (file:line under /root/reference/src/open_clip).  A reference-side binding is plain ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers + sizes; the caller owns all memory (device pointers unless stated otherwise);
+ *     the library never allocates.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (async).
+ *   - re-entrant, no global device state (the backward pass runs on the autograd thread).
+ *   - return 0 on success, negative ocn_status on error; ocn_last_error() holds the message
+ *     (thread-local).  Python wrappers turn that into RuntimeError, like the reference's asserts.
+ *   - "bf16" buffers are raw 16-bit bfloat16; residual stream, statistics, losses and weight
+ *     gradients are fp32.
+ */
+#ifndef OPENCLIP_HIP_H
+#define OPENCLIP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ocn_stream_t; /* hipStream_t */
+
+enum ocn_status { OCN_OK = 0, OCN_ERR_INVALID = -1, OCN_ERR_LAUNCH = -2, OCN_ERR_UNSUPPORTED = -3 };
+
+/* epilogues of ocn_gemm_nt */
+enum ocn_epilogue {
+    OCN_EPI_BF16 = 0,           /* out_bf16 = alpha*acc + bias                                            */
+    OCN_EPI_BIAS_GELU = 1,      /* aux_bf16 = acc + bias (pre-activation, saved); out_bf16 = gelu(acc+bias) */
+    OCN_EPI_BIAS_RESID_F32 = 2, /* out_f32 = resid_f32 + acc + bias                                       */
+    OCN_EPI_DGELU = 3,          /* out_bf16 = acc * gelu'(aux_bf16)                                       */
+    OCN_EPI_F32 = 4             /* out_f32 = alpha*acc + bias                                             */
+};
+
+const char* ocn_last_error(void);
+int ocn_version(void);
+
+/* ---- GEMMs (MFMA v_mfma_f32_32x32x16_bf16, fp32 accumulate) ------------------------------------
+ * ocn_gemm_nt: C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  Replaces F.linear
+ *   (transformer.py:169 in_proj, :246 out_proj, :295-299 c_fc + nn.GELU + c_proj), the residual adds of
+ *   transformer.py:328-329, `pooled @ proj` (:923), `x @ text_projection` (model.py:409), the logit
+ *   matmul (loss.py:103-110) and every dgrad of the backward (a17).  K % 64 == 0; A, B bf16 row-major.
+ *   bias [N] fp32 or NULL; resid fp32 [M,ldc] (EPI 2); aux bf16 [M,ldc] (EPI 1: written, EPI 3: read). */
+int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* out, int ldc, int M, int N, int K,
+                const float* bias, const float* resid, void* aux, float alpha, ocn_stream_t stream);
+
+/* ocn_gemm_tn_accum: dW[N,K] += alpha * A[M,N]^T . B[M,K]  (fp32 atomics into dW, which the caller zeroes or
+ *   pre-loads); if dbias != NULL also dbias[N] += alpha * colsum(A).  The wgrad + bias-grad of every Linear
+ *   (autograd of transformer.py:169,246,295-299) and the G^T products of the loss backward.
+ *   N % 8 == 0, K % 8 == 0; M arbitrary. */
+int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
+                      float* dbias, float alpha, ocn_stream_t stream);
+
+/* ---- casts -------------------------------------------------------------------------------------
+ * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */
+int ocn_cast_f32_bf16(const float* src, void* dst, int64_t n, ocn_stream_t stream);
+/* dst[C,R] (bf16) = transpose(src[R,C] fp32): weight copies laid out for the NT dgrad / `@ proj` GEMMs */
+int ocn_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, ocn_stream_t stream);
+
+/* ---- LayerNorm (layers.py:20-26, eps 1e-5; fp32 statistics) ------------------------------------
+ * fwd: y = (x-mean)*rstd*w + b over the last dim C (C % 4 == 0, C <= 2048); writes y as bf16 and/or fp32
+ *      (either pointer may be NULL) and mean/rstd [M] for the backward.
+ * bwd: dx = LN'(dy) (+ dres if non-NULL: the residual branch's gradient), written as fp32 and/or bf16;
+ *      dw[C] += sum_rows dy*xhat, db[C] += sum_rows dy (fp32 atomics; caller zeroes).
+ *      dy is bf16 (dy_is_f32 = 0) or fp32 (1). */
+int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+                      float* rstd, int M, int C, float eps, ocn_stream_t stream);
+int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
+                      const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, int M,
+                      int C, ocn_stream_t stream);
+
+/* ---- attention core (transformer.py:199-244: head split + F.scaled_dot_product_attention) ------
+ * qkv bf16 [B*L, 3*H*64] (q | k | v column blocks, heads contiguous inside each: the layout F.linear with
+ * in_proj_weight produces, transformer.py:169); out bf16 [B*L, H*64]; lse fp32 [B*H*L] (natural log).
+ * head_dim is 64; L <= 128.  causal != 0 applies the text tower's upper-triangular -inf mask
+ * (transformer.py:1716-1722) as a predicate. */
+int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int causal, float scale,
+                 ocn_stream_t stream);
+int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L, int H,
+                 int causal, float scale, ocn_stream_t stream);
+
+/* ---- image tower embedding (transformer.py:793-808) -------------------------------------------
+ * patchify: image [B,3,H,W] (fp32, or bf16 when image_is_bf16) -> patches bf16 [B*gh*gw, Kpad], column order
+ *   (c, i, j) = conv1.weight.reshape(width, 3*P*P) (transformer.py:632-638, :794-796); zero-padded to Kpad.
+ * embed_assemble_fwd: emb[b,0,:] = cls + pos[0]; emb[b,1+g,:] = patch_out[b*G+g,:] + pos[1+g]  (:799-801)
+ * embed_assemble_bwd: dpatch bf16 [B*G, C] = demb[b,1+g,:]; dpos[T,C] += sum_b demb; dcls[C] += sum_b demb[b,0] */
+int ocn_patchify(const void* image, int image_is_bf16, void* patches, int B, int H, int W, int P, int Kpad,
+                 ocn_stream_t stream);
+int ocn_embed_assemble_fwd(const float* patch_out, const float* cls, const float* pos, float* emb, int B, int G, int C,
+                           ocn_stream_t stream);
+int ocn_embed_assemble_bwd(const float* demb, void* dpatch_bf16, float* dpos, float* dcls, int B, int G, int C,
+                           ocn_stream_t stream);
+
+/* ---- text tower embedding (model.py:399-401) ---------------------------------------------------
+ * fwd: x[b,l,:] = table[text[b,l],:] + pos[l,:];  bwd: dtable[text[b,l],:] += dx[b,l,:] (fp32 atomics),
+ * dpos[l,:] += sum_b dx[b,l,:].  text is int64. */
+int ocn_token_embed_fwd(const int64_t* text, const float* table, const float* pos, float* x, int B, int L, int C,
+                        int vocab, ocn_stream_t stream);
+int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* dtable, float* dpos, int B, int L, int C, int vocab,
+                        ocn_stream_t stream);
+
+/* ---- pooling (transformer.py:786-787 'tok'; :941-944 'argmax') ---------------------------------
+ * argmax_rows: idx[b] = first index of max(text[b,:]) (torch.argmax semantics)
+ * gather_rows: out[b,:] = x[(b*L + idx[b]),:] (idx NULL -> token 0);  scatter_rows: dx (pre-zeroed)[b*L+idx[b],:] = d[b,:] */
+int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, ocn_stream_t stream);
+int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream);
+int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
+                     ocn_stream_t stream);
+
+/* ---- F.normalize (model.py:391,411; eps 1e-12) -------------------------------------------------
+ * fwd: y = x / max(||x||, eps) as fp32 and bf16, inv_norm[B] saved; bwd: dx = (dy - y*(y.dy)) * inv_norm */
+int ocn_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int B, int E, float eps, ocn_stream_t stream);
+int ocn_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int B, int E, ocn_stream_t stream);
+
+/* ---- contrastive losses on materialised logits -------------------------------------------------
+ * softmax CE rows (F.cross_entropy(logits, arange+offset), loss.py:78-89,136-139): for each of R rows of
+ *   logits fp32 [R,N]: lse, loss_sum += (lse - logits[r, r+label_offset]) * loss_scale; writes
+ *   G bf16 [R,N] = (softmax - onehot) * grad_scale; dscale_sum += sum(G*logits) * inv_logit_scale.
+ * siglip (loss.py:344-367): z = labels*logits (labels -1 off-diagonal, +1 on (r, r+label_offset) unless
+ *   negative_only); loss_sum += -logsigmoid(z)*loss_scale; G = -labels*sigmoid(-z)*grad_scale;
+ *   dscale_sum += sum(G*(logits-bias))*inv_logit_scale; dbias_sum += sum(G). */
+int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, float loss_scale,
+                        float grad_scale, float inv_logit_scale, float* loss_sum, float* dscale_sum,
+                        ocn_stream_t stream);
+int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,
+                    float bias, float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
+                    float* dscale_sum, float* dbias_sum, ocn_stream_t stream);
+
+/* ---- optimizer (train.py:181-182, image_text_task.py:91-101) --------------
+ * sumsq: out[0] += sum(x^2) (grad-norm for clip_grad_norm_);
+ * adamw_step: torch.optim.AdamW semantics (decoupled weight decay, bias correction), optional grad scale
+ *   (clip coefficient read from device pointer clip_coef or 1.0 when NULL); also refreshes the bf16 shadow
+ *   copy when w_bf16 != NULL. */
+int ocn_sumsq_accum(const float* x, int64_t n, float* out, ocn_stream_t stream);
+int ocn_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, const float* clip_coef, ocn_stream_t stream);
+
+/* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
+int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,
+                     ocn_stream_t stream);
+int ocn_probe_tr16(const void* in_bf16 /*[16 rows][32 cols]*/, void* out_bf16 /*[64 lanes][4]*/, ocn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,81 @@
+"""ctypes binding of ``libopenclip_hip.so`` (C ABI: include/openclip_hip.h).
+
+The product path has NO fallback: if the shared library is missing ``load()`` raises, and every op in
+``open_clip_amd.ops`` goes through ``call()``.  ``SIGNATURES`` mirrors the header one-to-one
+(tests/test_cabi.py checks header <-> table <-> exported symbols).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopenclip_hip.so")
+
+_p, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> argtypes (every function returns int status unless listed in _SPECIAL)
+SIGNATURES = {
+    "ocn_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p],
+    "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
+    "ocn_cast_f32_bf16": [_p, _p, _l, _p],
+    "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
+    "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "ocn_embed_assemble_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "ocn_embed_assemble_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "ocn_token_embed_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ocn_token_embed_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ocn_argmax_rows": [_p, _p, _i, _i, _p],
+    "ocn_gather_rows": [_p, _p, _p, _i, _i, _i, _p],
+    "ocn_scatter_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "ocn_l2norm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "ocn_l2norm_bwd": [_p, _p, _p, _p, _i, _i, _p],
+    "ocn_softmax_ce_rows": [_p, _i, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p],
+    "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p],
+    "ocn_sumsq_accum": [_p, _l, _p, _p],
+    "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
+    "ocn_probe_mfma32": [_p, _p, _p, _p],
+    "ocn_probe_tr16": [_p, _p, _p],
+}
+_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i)}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Loads the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no fallback path). "
+                "Build it with `python -m open_clip_amd.build` (needs hipcc, cross-compiles for gfx950)."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _i
+        for name, (argtypes, restype) in _SPECIAL.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Calls ``name`` and raises RuntimeError(ocn_last_error()) on a non-zero status
+    (the reference's convention is Python exceptions / asserts, e.g. factory.py:416, loss.py:37)."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.ocn_last_error().decode()}")

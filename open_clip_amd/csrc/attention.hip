@@ -1,0 +1,350 @@
+// Multi-head self-attention core for the CLIP towers (sequence 50 / 77 / 257, head_dim 64) on gfx950.
+//
+// One workgroup per (batch, head); one wave per 32-query block.  K and V (and, in the backward, Q and dO)
+// of the head are staged once into LDS by LDS-DMA as row-major [L_pad][64] bf16 images (128-byte rows,
+// chunk-swizzled, see swz_nt) and are consumed two ways from the same image:
+//   * d-contiguous MFMA operands by ds_read_b128   (K in S^T = K Q^T,  V in dP^T = V dO^T, ...)
+//   * key-/query-contiguous (transposed) operands by ds_read_b64_tr_b16   (V^T in O^T = V^T P^T, K^T, Q^T, dO^T)
+// All products are computed "swapped" (S^T = K Q^T, O^T = V^T P^T) so that a lane owns one query (forward,
+// dQ) or one key (dK/dV) and the softmax statistics stay lane-local: the row max / sum need one cross-half
+// exchange, and the C-layout registers of S^T are directly the B operand of the second product
+// (k-slot (h,e) of step t <-> accumulator register 8t+e <-> key 32kb + 16t + 8(e>>2) + 4h + (e&3)).
+// Softmax in fp32 (exp2 domain); the causal mask of the text tower is a predicate, not a tensor.
+#include "ocn_common.h"
+
+namespace {
+
+OCN_DEV int swz_nt(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// stage rows [0, LP) (clamped to L-1) of one head's 64-wide column block into LDS; all waves cooperate
+OCN_DEV void stage_head(const bf16* __restrict__ base, size_t row_stride, int L, int LP, char* sT, int wave, int nwaves, int lane) {
+    for (int seg = wave; seg < LP / 8; seg += nwaves) {
+        const int r = seg * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz_nt(r);
+        const int gr = r < L ? r : L - 1;
+        glds16(base + (size_t)gr * row_stride + c * 8, (OCN_LDS void*)(sT + seg * 1024));
+    }
+}
+
+// d-contiguous operand: row `row` of the image, k-step s (16 of the 64 d's), this lane's 8 d's
+OCN_DEV bf16x8 frag_rows(const char* sT, int row, int s, int lane) {
+    const int c = (s * 2 + (lane >> 5)) ^ swz_nt(row);
+    return *(const bf16x8*)(sT + row * 128 + (c << 4));
+}
+
+// transposed operand: A[i = d (dblk*32 + lane&31)][k-slots <-> rows rbase + 16t + 8(e>>2) + 4h + (e&3)]
+OCN_DEV bf16x8 frag_cols(const char* sT, int rbase, int t, int dblk, int lane) {
+    const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const int chunk = dblk * 4 + g * 2 + ((i & 3) >> 1);
+    const int r0 = rbase + 16 * t + 4 * h + (i >> 2);
+    const int r1 = r0 + 8;
+    const s16x4 lo = lds_read_tr16((const OCN_LDS void*)(sT + r0 * 128 + ((chunk ^ swz_nt(r0)) << 4) + (i & 1) * 8));
+    const s16x4 hi = lds_read_tr16((const OCN_LDS void*)(sT + r1 * 128 + ((chunk ^ swz_nt(r1)) << 4) + (i & 1) * 8));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+OCN_DEV bf16x8 pack8(const f32x16& p, int t) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(p[8 * t + e]);
+    return o;
+}
+
+OCN_DEV f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                         float* __restrict__ lse, int L, int H, int causal, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int LP = nwaves * 32;
+    const int b = blockIdx.x / H, hd = blockIdx.x % H;
+    const int C = H * 64;
+    const size_t rs = (size_t)3 * C;
+    const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
+    char* sK = smem;
+    char* sV = smem + LP * 128;
+    stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
+    stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
+
+    const int qb = wave;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int query = qb * 32 + lr;
+    const int qrow = query < L ? query : L - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qbase + (size_t)qrow * rs + s * 16 + lh * 8);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float sc = scale * LOG2E;
+    float m = -1e30f, l = 0.f;
+    f32x16 o0 = zero16(), o1 = zero16();
+    const int nkb = causal ? qb + 1 : nwaves;
+    for (int kb = 0; kb < nkb; ++kb) {
+        f32x16 st = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st = mfma32(frag_rows(sK, kb * 32 + lr, s, lane), qf[s], st);
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + mfma32_row(r, lane);
+            const bool ok = key < L && (!causal || key <= query);
+            st[r] = ok ? st[r] * sc : -INFINITY;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = exp2f(st[r] - mn);
+            ps += st[r];
+        }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16x8 pf = pack8(st, t);
+            o0 = mfma32(frag_cols(sV, kb * 32, t, 0, lane), pf, o0);
+            o1 = mfma32(frag_cols(sV, kb * 32, t, 1, lane), pf, o1);
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (query < L) {
+        bf16* orow = out + ((size_t)b * L + query) * C + hd * 64;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int d = 8 * q4 + 4 * lh;
+            bf16x4 v0 = {f2bf(o0[4 * q4] * inv), f2bf(o0[4 * q4 + 1] * inv), f2bf(o0[4 * q4 + 2] * inv), f2bf(o0[4 * q4 + 3] * inv)};
+            bf16x4 v1 = {f2bf(o1[4 * q4] * inv), f2bf(o1[4 * q4 + 1] * inv), f2bf(o1[4 * q4 + 2] * inv), f2bf(o1[4 * q4 + 3] * inv)};
+            *(bf16x4*)(orow + d) = v0;
+            *(bf16x4*)(orow + 32 + d) = v1;
+        }
+        if (lh == 0) lse[((size_t)b * H + hd) * L + query] = (m + log2f(l)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+OCN_DEV void store_t(bf16* base, size_t row_stride, int row, int L, int lh, const f32x16& a0, const f32x16& a1) {
+    if (row >= L) return;
+    bf16* p = base + (size_t)row * row_stride;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = 8 * q4 + 4 * lh;
+        bf16x4 v0 = {f2bf(a0[4 * q4]), f2bf(a0[4 * q4 + 1]), f2bf(a0[4 * q4 + 2]), f2bf(a0[4 * q4 + 3])};
+        bf16x4 v1 = {f2bf(a1[4 * q4]), f2bf(a1[4 * q4 + 1]), f2bf(a1[4 * q4 + 2]), f2bf(a1[4 * q4 + 3])};
+        *(bf16x4*)(p + d) = v0;
+        *(bf16x4*)(p + 32 + d) = v1;
+    }
+}
+
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                         const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                         bf16* __restrict__ dqkv, int L, int H, int causal, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int LP = nwaves * 32;
+    const int b = blockIdx.x / H, hd = blockIdx.x % H;
+    const int C = H * 64;
+    const size_t rs = (size_t)3 * C;
+    const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
+    const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
+    const bf16* obase = out + (size_t)b * L * C + hd * 64;
+    char* sQ = smem;
+    char* sK = smem + LP * 128;
+    char* sV = smem + 2 * LP * 128;
+    char* sdO = smem + 3 * LP * 128;
+    float* sLse = (float*)(smem + 4 * LP * 128);
+    float* sDelta = sLse + LP;
+    stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
+    stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
+    stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
+    stage_head(dobase, (size_t)C, L, LP, sdO, wave, nwaves, lane);
+    // delta[q] = sum_d dO[q,d] * O[q,d]; lse in exp2 units
+    for (int idx = threadIdx.x; idx < LP * 8; idx += blockDim.x) {
+        const int r = idx >> 3, c = idx & 7;
+        const int gr = r < L ? r : L - 1;
+        const bf16x8 a = *(const bf16x8*)(dobase + (size_t)gr * C + c * 8);
+        const bf16x8 o = *(const bf16x8*)(obase + (size_t)gr * C + c * 8);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(o[e]);
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (c == 0) {
+            sDelta[r] = d;
+            sLse[r] = lse[((size_t)b * H + hd) * L + gr] * LOG2E;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const float sc = scale * LOG2E;
+
+    // ---- phase A: dQ for query block `wave` (lane <-> query, registers <-> keys) ----
+    {
+        const int qb = wave;
+        const int query = qb * 32 + lr;
+        const float lse_q = sLse[query], delta_q = sDelta[query];
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = frag_rows(sQ, query, s, lane);
+            dof[s] = frag_rows(sdO, query, s, lane);
+        }
+        f32x16 dq0 = zero16(), dq1 = zero16();
+        const int nkb = causal ? qb + 1 : nwaves;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = mfma32(frag_rows(sK, kb * 32 + lr, s, lane), qf[s], st);
+                dp = mfma32(frag_rows(sV, kb * 32 + lr, s, lane), dof[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + mfma32_row(r, lane);
+                const bool ok = key < L && query < L && (!causal || key <= query);
+                const float p = ok ? exp2f(st[r] * sc - lse_q) : 0.f;
+                st[r] = p * (dp[r] - delta_q) * scale;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 dsf = pack8(st, t);
+                dq0 = mfma32(frag_cols(sK, kb * 32, t, 0, lane), dsf, dq0);
+                dq1 = mfma32(frag_cols(sK, kb * 32, t, 1, lane), dsf, dq1);
+            }
+        }
+        store_t(dqkv + (size_t)b * L * rs + hd * 64, rs, query, L, lh, dq0, dq1);
+    }
+
+    // ---- phase B: dK, dV for key block `wave` (lane <-> key, registers <-> queries) ----
+    {
+        const int kb = wave;
+        const int key = kb * 32 + lr;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = frag_rows(sK, key, s, lane);
+            vf[s] = frag_rows(sV, key, s, lane);
+        }
+        f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+        const int qb0 = causal ? kb : 0;
+        for (int qb = qb0; qb < nwaves; ++qb) {
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = mfma32(frag_rows(sQ, qb * 32 + lr, s, lane), kf[s], st);
+                dp = mfma32(frag_rows(sdO, qb * 32 + lr, s, lane), vf[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int query = qb * 32 + mfma32_row(r, lane);
+                const bool ok = key < L && query < L && (!causal || key <= query);
+                const float p = ok ? exp2f(st[r] * sc - sLse[query]) : 0.f;
+                dp[r] = p * (dp[r] - sDelta[query]) * scale;
+                st[r] = p;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 pf = pack8(st, t), dsf = pack8(dp, t);
+                dv0 = mfma32(frag_cols(sdO, qb * 32, t, 0, lane), pf, dv0);
+                dv1 = mfma32(frag_cols(sdO, qb * 32, t, 1, lane), pf, dv1);
+                dk0 = mfma32(frag_cols(sQ, qb * 32, t, 0, lane), dsf, dk0);
+                dk1 = mfma32(frag_cols(sQ, qb * 32, t, 1, lane), dsf, dk1);
+            }
+        }
+        bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
+        store_t(dbase + C, rs, key, L, lh, dk0, dk1);
+        store_t(dbase + 2 * C, rs, key, L, lh, dv0, dv1);
+    }
+}
+
+int check_attn(const char* name, int B, int L, int H) {
+    OCN_CHECK_ARG(B > 0 && H > 0 && L > 0, "%s: bad shape B=%d L=%d H=%d", name, B, L, H);
+    OCN_CHECK_ARG(L <= 320, "%s: L=%d > 320 unsupported", name, L);
+    return OCN_OK;
+}
+
+}  // namespace
+
+extern "C" int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int causal, float scale,
+                            ocn_stream_t stream) {
+    OCN_CHECK_ARG(qkv && out && lse, "ocn_attn_fwd: null operand");
+    if (int e = check_attn("ocn_attn_fwd", B, L, H)) return e;
+    const int nw = ocn_cdiv(L, 32);
+    const int lds = 2 * nw * 32 * 128;
+    if (nw <= 4) {
+        hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (bf16*)out, lse, L, H, causal, scale);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_fwd_kernel<640>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (bf16*)out, lse, L, H, causal, scale);
+    }
+    OCN_CHECK_LAUNCH("ocn_attn_fwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L,
+                            int H, int causal, float scale, ocn_stream_t stream) {
+    OCN_CHECK_ARG(qkv && out && dout && lse && dqkv, "ocn_attn_bwd: null operand");
+    if (int e = check_attn("ocn_attn_bwd", B, L, H)) return e;
+    const int nw = ocn_cdiv(L, 32);
+    const int lds = 4 * nw * 32 * 128 + 2 * nw * 32 * 4;
+    OCN_CHECK_ARG(lds <= 160 * 1024, "ocn_attn_bwd: L=%d needs %d bytes of LDS (> 160 KiB)", L, lds);
+    if (nw <= 4) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_kernel<256>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_kernel<640>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale);
+    }
+    OCN_CHECK_LAUNCH("ocn_attn_bwd");
+    return OCN_OK;
+}

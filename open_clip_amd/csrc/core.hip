@@ -1,0 +1,56 @@
+// Error plumbing, version, and the two hardware-layout probes the tests use.
+#include "ocn_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void ocn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ocn_last_error(void) { return g_err; }
+extern "C" int ocn_version(void) { return 100; }
+
+namespace {
+// C[32,32] = A[32,16] . B[32,16]^T with ONE v_mfma_f32_32x32x16_bf16 -- pins operand/accumulator lane maps
+__global__ void probe_mfma32_kernel(const bf16* a, const bf16* b, float* c) {
+    const int lane = threadIdx.x;
+    const bf16x8 af = *(const bf16x8*)(a + (lane & 31) * 16 + (lane >> 5) * 8);
+    const bf16x8 bq = *(const bf16x8*)(b + (lane & 31) * 16 + (lane >> 5) * 8);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma32(af, bq, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[mfma32_row(r, lane) * 32 + (lane & 31)] = acc[r];
+}
+
+// in: [16 rows][32 cols] bf16.  16-lane group g=(lane>>4)&1, half h=lane>>5: reads the 4x16 block at rows
+// 4*h*2.. (rows h*8 + 0..3), cols g*16.. ; lane i gives the address of [i>>2][(i&3)*4] and must get column i.
+__global__ void probe_tr16_kernel(const bf16* in, bf16* out) {
+    __shared__ __attribute__((aligned(16))) bf16 s[16 * 32];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < 16 * 32; k += 64) s[k] = in[k];
+    __syncthreads();
+    const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const bf16* p = s + (h * 8 + (i >> 2)) * 32 + g * 16 + (i & 3) * 4;
+    const s16x4 v = lds_read_tr16((const OCN_LDS void*)p);
+    *(s16x4*)(out + lane * 4) = v;
+}
+}  // namespace
+
+extern "C" int ocn_probe_mfma32(const void* a, const void* b, float* c, ocn_stream_t stream) {
+    hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, c);
+    OCN_CHECK_LAUNCH("ocn_probe_mfma32");
+    return OCN_OK;
+}
+extern "C" int ocn_probe_tr16(const void* in, void* out, ocn_stream_t stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)in, (bf16*)out);
+    OCN_CHECK_LAUNCH("ocn_probe_tr16");
+    return OCN_OK;
+}

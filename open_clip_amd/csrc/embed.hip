@@ -1,0 +1,301 @@
+// HBM-bound embedding / pooling / normalisation kernels around the two transformer stacks.
+#include "ocn_common.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+// ---- patchify: image [B,3,H,W] -> patches bf16 [B*gh*gw, Kpad], column = c*P*P + i*P + j ------
+template <typename T, int VEC>
+__global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ out, int B, int H, int W, int P, int Kpad,
+                                long total) {
+    const int gh = H / P, gw = W / P, KP = 3 * P * P, kv = Kpad / VEC;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / kv;
+        const int k = (int)(idx % kv) * VEC;
+        bf16* o = out + row * Kpad + k;
+        if (k >= KP) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (bf16)0.f;
+            continue;
+        }
+        const int c = k / (P * P), rem = k % (P * P), i = rem / P, j = rem % P;
+        const int b = (int)(row / (gh * gw)), g = (int)(row % (gh * gw)), py = g / gw, px = g % gw;
+        const T* s = img + (((size_t)b * 3 + c) * H + py * P + i) * W + px * P + j;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = f2bf((float)s[e]);
+    }
+}
+
+// ---- class token + positional embedding (transformer.py:799-801) --------------------------------
+__global__ void embed_assemble_fwd_kernel(const float* __restrict__ po, const float* __restrict__ cls,
+                                          const float* __restrict__ pos, float* __restrict__ emb, int B, int G, int C) {
+    const int T = G + 1, c4n = C / 4;
+    const long total = (long)B * T * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long bt = idx / c4n;
+        const int t = (int)(bt % T);
+        const long b = bt / T;
+        const f32x4 p = *(const f32x4*)(pos + (size_t)t * C + c);
+        const f32x4 v = (t == 0) ? *(const f32x4*)(cls + c) : *(const f32x4*)(po + ((size_t)b * G + t - 1) * C + c);
+        *(f32x4*)(emb + (size_t)bt * C + c) = v + p;
+    }
+}
+
+// grid.x covers (t, c4); grid.y = batch chunks.  dpos/dcls by fp32 atomics (one per chunk per element).
+__global__ void embed_assemble_bwd_kernel(const float* __restrict__ demb, bf16* __restrict__ dpatch,
+                                          float* __restrict__ dpos, float* __restrict__ dcls, int B, int G, int C, int bchunk) {
+    const int T = G + 1, c4n = C / 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * c4n) return;
+    const int t = idx / c4n, c = (idx % c4n) * 4;
+    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0; b < b1; ++b) {
+        const f32x4 v = *(const f32x4*)(demb + ((size_t)b * T + t) * C + c);
+        acc = acc + v;
+        if (t > 0) {
+            bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)(dpatch + ((size_t)b * G + t - 1) * C + c) = o4;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsafeAtomicAdd(dpos + (size_t)t * C + c + e, acc[e]);
+        if (t == 0) unsafeAtomicAdd(dcls + c + e, acc[e]);
+    }
+}
+
+// ---- token embedding (model.py:399-401) ----------------------------------------------------------
+__global__ void token_embed_fwd_kernel(const int64_t* __restrict__ text, const float* __restrict__ table,
+                                       const float* __restrict__ pos, float* __restrict__ x, int B, int L, int C, int vocab) {
+    const int c4n = C / 4;
+    const long total = (long)B * L * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long bl = idx / c4n;
+        const int l = (int)(bl % L);
+        long tok = text[bl];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        *(f32x4*)(x + (size_t)bl * C + c) = *(const f32x4*)(table + (size_t)tok * C + c) + *(const f32x4*)(pos + (size_t)l * C + c);
+    }
+}
+
+__global__ void token_embed_bwd_kernel(const int64_t* __restrict__ text, const float* __restrict__ dx,
+                                       float* __restrict__ dtable, float* __restrict__ dpos, int B, int L, int C, int vocab,
+                                       int bchunk) {
+    const int c4n = C / 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L * c4n) return;
+    const int l = idx / c4n, c = (idx % c4n) * 4;
+    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0; b < b1; ++b) {
+        const f32x4 v = *(const f32x4*)(dx + ((size_t)b * L + l) * C + c);
+        acc = acc + v;
+        long tok = text[(size_t)b * L + l];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        float* d = dtable + (size_t)tok * C + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d + e, v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dpos + (size_t)l * C + c + e, acc[e]);
+}
+
+// ---- pooling ---------------------------------------------------------------------------------------
+__global__ void argmax_rows_kernel(const int64_t* __restrict__ text, int32_t* __restrict__ idx, int B, int L) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    long best = INT64_MIN;
+    int bi = 0x7fffffff;
+    for (int l = lane; l < L; l += 64) {
+        const long v = text[(size_t)row * L + l];
+        if (v > best) {  // ascending l per lane: keeps the first index of this lane's max
+            best = v;
+            bi = l;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) idx[row] = bi;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                   int B, int L, int C) {
+    const int c4n = C / 4;
+    const long total = (long)B * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long b = i / c4n;
+        const int t = idx ? idx[b] : 0;
+        *(f32x4*)(out + (size_t)b * C + c) = *(const f32x4*)(x + ((size_t)b * L + t) * C + c);
+    }
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ d, const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                    bf16* __restrict__ dx16, int B, int L, int C) {
+    const int c4n = C / 4;
+    const long total = (long)B * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long b = i / c4n;
+        const int t = idx ? idx[b] : 0;
+        const f32x4 v = *(const f32x4*)(d + (size_t)b * C + c);
+        const size_t o = ((size_t)b * L + t) * C + c;
+        if (dx) *(f32x4*)(dx + o) = v;
+        if (dx16) {
+            bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)(dx16 + o) = o4;
+        }
+    }
+}
+
+// ---- F.normalize ---------------------------------------------------------------------------------------
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, bf16* __restrict__ y16,
+                                  float* __restrict__ inv_norm, int B, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float s = 0.f;
+    for (int c = lane; c < E; c += 64) {
+        const float v = x[(size_t)row * E + c];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);
+    if (lane == 0) inv_norm[row] = inv;
+    for (int c = lane; c < E; c += 64) {
+        const float v = x[(size_t)row * E + c] * inv;
+        y[(size_t)row * E + c] = v;
+        if (y16) y16[(size_t)row * E + c] = f2bf(v);
+    }
+}
+
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ inv_norm,
+                                  float* __restrict__ dx, int B, int E) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float s = 0.f;
+    for (int c = lane; c < E; c += 64) s += dy[(size_t)row * E + c] * y[(size_t)row * E + c];
+    s = wave_sum(s);
+    const float inv = inv_norm[row];
+    for (int c = lane; c < E; c += 64) dx[(size_t)row * E + c] = (dy[(size_t)row * E + c] - y[(size_t)row * E + c] * s) * inv;
+}
+
+int grid_for(long items, int block) {
+    long g = (items + block - 1) / block;
+    return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
+}
+
+}  // namespace
+
+extern "C" int ocn_patchify(const void* image, int image_is_bf16, void* patches, int B, int H, int W, int P, int Kpad,
+                            ocn_stream_t stream) {
+    OCN_CHECK_ARG(image && patches, "ocn_patchify: null operand");
+    OCN_CHECK_ARG(B > 0 && P > 0 && H % P == 0 && W % P == 0 && P % 2 == 0, "ocn_patchify: bad geometry H=%d W=%d P=%d", H, W, P);
+    OCN_CHECK_ARG(Kpad >= 3 * P * P && Kpad % 4 == 0, "ocn_patchify: Kpad=%d too small / not a multiple of 4", Kpad);
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)B * (H / P) * (W / P);
+    if (P % 4 == 0) {
+        const long total = rows * (Kpad / 4);
+        if (image_is_bf16) hipLaunchKernelGGL((patchify_kernel<bf16, 4>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16*)image, (bf16*)patches, B, H, W, P, Kpad, total);
+        else hipLaunchKernelGGL((patchify_kernel<float, 4>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const float*)image, (bf16*)patches, B, H, W, P, Kpad, total);
+    } else {
+        const long total = rows * (Kpad / 2);
+        if (image_is_bf16) hipLaunchKernelGGL((patchify_kernel<bf16, 2>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16*)image, (bf16*)patches, B, H, W, P, Kpad, total);
+        else hipLaunchKernelGGL((patchify_kernel<float, 2>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const float*)image, (bf16*)patches, B, H, W, P, Kpad, total);
+    }
+    OCN_CHECK_LAUNCH("ocn_patchify");
+    return OCN_OK;
+}
+
+extern "C" int ocn_embed_assemble_fwd(const float* patch_out, const float* cls, const float* pos, float* emb, int B, int G,
+                                      int C, ocn_stream_t stream) {
+    OCN_CHECK_ARG(patch_out && cls && pos && emb, "ocn_embed_assemble_fwd: null operand");
+    OCN_CHECK_ARG(B > 0 && G > 0 && C % 4 == 0, "ocn_embed_assemble_fwd: bad shape");
+    const long total = (long)B * (G + 1) * (C / 4);
+    hipLaunchKernelGGL(embed_assemble_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, patch_out, cls, pos, emb, B, G, C);
+    OCN_CHECK_LAUNCH("ocn_embed_assemble_fwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_embed_assemble_bwd(const float* demb, void* dpatch_bf16, float* dpos, float* dcls, int B, int G, int C,
+                                      ocn_stream_t stream) {
+    OCN_CHECK_ARG(demb && dpatch_bf16 && dpos && dcls, "ocn_embed_assemble_bwd: null operand");
+    OCN_CHECK_ARG(B > 0 && G > 0 && C % 4 == 0, "ocn_embed_assemble_bwd: bad shape");
+    const int bchunk = 32;
+    dim3 grid(ocn_cdiv((long)(G + 1) * (C / 4), 256), ocn_cdiv(B, bchunk));
+    hipLaunchKernelGGL(embed_assemble_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, demb, (bf16*)dpatch_bf16, dpos, dcls, B, G, C, bchunk);
+    OCN_CHECK_LAUNCH("ocn_embed_assemble_bwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_token_embed_fwd(const int64_t* text, const float* table, const float* pos, float* x, int B, int L, int C,
+                                   int vocab, ocn_stream_t stream) {
+    OCN_CHECK_ARG(text && table && pos && x, "ocn_token_embed_fwd: null operand");
+    OCN_CHECK_ARG(B > 0 && L > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_fwd: bad shape");
+    const long total = (long)B * L * (C / 4);
+    hipLaunchKernelGGL(token_embed_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, text, table, pos, x, B, L, C, vocab);
+    OCN_CHECK_LAUNCH("ocn_token_embed_fwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* dtable, float* dpos, int B, int L, int C,
+                                   int vocab, ocn_stream_t stream) {
+    OCN_CHECK_ARG(text && dx && dtable && dpos, "ocn_token_embed_bwd: null operand");
+    OCN_CHECK_ARG(B > 0 && L > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_bwd: bad shape");
+    const int bchunk = 32;
+    dim3 grid(ocn_cdiv((long)L * (C / 4), 256), ocn_cdiv(B, bchunk));
+    hipLaunchKernelGGL(token_embed_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, text, dx, dtable, dpos, B, L, C, vocab, bchunk);
+    OCN_CHECK_LAUNCH("ocn_token_embed_bwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, ocn_stream_t stream) {
+    OCN_CHECK_ARG(text && idx && B > 0 && L > 0, "ocn_argmax_rows: bad arguments");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(ocn_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, text, idx, B, L);
+    OCN_CHECK_LAUNCH("ocn_argmax_rows");
+    return OCN_OK;
+}
+
+extern "C" int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream) {
+    OCN_CHECK_ARG(x && out && B > 0 && L > 0 && C % 4 == 0, "ocn_gather_rows: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, L, C);
+    OCN_CHECK_LAUNCH("ocn_gather_rows");
+    return OCN_OK;
+}
+
+extern "C" int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
+                                ocn_stream_t stream) {
+    OCN_CHECK_ARG(d && (dx || dx_bf16) && B > 0 && L > 0 && C % 4 == 0, "ocn_scatter_rows: bad arguments");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, d, idx, dx, (bf16*)dx_bf16, B, L, C);
+    OCN_CHECK_LAUNCH("ocn_scatter_rows");
+    return OCN_OK;
+}
+
+extern "C" int ocn_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int B, int E, float eps,
+                              ocn_stream_t stream) {
+    OCN_CHECK_ARG(x && y && inv_norm && B > 0 && E > 0, "ocn_l2norm_fwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ocn_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, y, (bf16*)y_bf16, inv_norm, B, E, eps);
+    OCN_CHECK_LAUNCH("ocn_l2norm_fwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int B, int E,
+                              ocn_stream_t stream) {
+    OCN_CHECK_ARG(dy && y && inv_norm && dx && B > 0 && E > 0, "ocn_l2norm_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ocn_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx, B, E);
+    OCN_CHECK_LAUNCH("ocn_l2norm_bwd");
+    return OCN_OK;
+}

@@ -1,0 +1,216 @@
+// LayerNorm forward / backward over the last dimension (HBM-bound; fp32 statistics).
+// One wave per row, 16-byte vector accesses, rows grid-strided; the backward keeps per-lane partial sums
+// of dgamma/dbeta in registers across its rows, folds the 4 waves of a workgroup through LDS and issues one
+// fp32 atomic per column per workgroup.
+// Algorithmic bytes per row of C columns: fwd 4C (x fp32) + 2C (y bf16) [+4C if y fp32];
+// bwd 2C|4C (dy) + 4C (x) [+4C dres] + 4C (dx fp32) + 2C (dx bf16).
+#include "ocn_common.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, bf16* __restrict__ y16,
+                                                      float* __restrict__ y32, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invC = 1.0f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * C;
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) v[i] = *(const f32x4*)(xr + c); else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) * invC + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                const f32x4 wv = *(const f32x4*)(w + c), bv = *(const f32x4*)(b + c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * wv[e] + bv[e];
+                if (y32) *(f32x4*)(y32 + (size_t)row * C + c) = o;
+                if (y16) {
+                    bf16x4 o4 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *(bf16x4*)(y16 + (size_t)row * C + c) = o4;
+                }
+            }
+        }
+    }
+}
+
+template <int NV, bool DY32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dyv, const float* __restrict__ x,
+                                                      const float* __restrict__ w, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                      float* __restrict__ dx32, bf16* __restrict__ dx16,
+                                                      float* __restrict__ dw, float* __restrict__ db, int M, int C) {
+    __shared__ float red[3][NV * 256 * 2];  // waves 1..3 -> wave 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invC = 1.0f / (float)C;
+    f32x4 aw[NV], ab[NV], wv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        aw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ab[i] = aw[i];
+        wv[i] = (c < C) ? *(const f32x4*)(w + c) : aw[i];
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], g[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            g[i] = xh[i];
+            if (c < C) {
+                const f32x4 xv = *(const f32x4*)(x + (size_t)row * C + c);
+                f32x4 dy;
+                if (DY32) {
+                    dy = *(const f32x4*)((const float*)dyv + (size_t)row * C + c);
+                } else {
+                    const bf16x4 d4 = *(const bf16x4*)((const bf16*)dyv + (size_t)row * C + c);
+                    dy = (f32x4){bf2f(d4[0]), bf2f(d4[1]), bf2f(d4[2]), bf2f(d4[3])};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    g[i][e] = dy[e] * wv[i][e];
+                    c1 += g[i][e];
+                    c2 += g[i][e] * xh[i][e];
+                    aw[i][e] += dy[e] * xh[i][e];
+                    ab[i][e] += dy[e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) * invC;
+        c2 = wave_sum(c2) * invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+                if (dres) o = o + *(const f32x4*)(dres + (size_t)row * C + c);
+                if (dx32) *(f32x4*)(dx32 + (size_t)row * C + c) = o;
+                if (dx16) {
+                    bf16x4 o4 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *(bf16x4*)(dx16 + (size_t)row * C + c) = o4;
+                }
+            }
+        }
+    }
+    // fold the 4 waves, then one atomic per column per workgroup
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[wave - 1][((i * 4 + e) * 64 + lane) * 2] = aw[i][e];
+                red[wave - 1][((i * 4 + e) * 64 + lane) * 2 + 1] = ab[i][e];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sw = aw[i][e], sb = ab[i][e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sw += red[k][((i * 4 + e) * 64 + lane) * 2];
+                    sb += red[k][((i * 4 + e) * 64 + lane) * 2 + 1];
+                }
+                if (c < C) {
+                    unsafeAtomicAdd(dw + c + e, sw);
+                    unsafeAtomicAdd(db + c + e, sb);
+                }
+            }
+        }
+    }
+}
+
+int ln_grid(int M) {
+    int g = ocn_cdiv(M, 4);
+    return g < 2048 ? g : 2048;
+}
+
+template <int NV>
+void launch_fwd(hipStream_t st, const float* x, const float* w, const float* b, bf16* y16, float* y32, float* mean, float* rstd,
+                int M, int C, float eps) {
+    ln_fwd_kernel<NV><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(x, w, b, y16, y32, mean, rstd, M, C, eps);
+}
+template <int NV>
+void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
+                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C) {
+    if (dy_is_f32) ln_bwd_kernel<NV, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+    else ln_bwd_kernel<NV, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+}
+
+}  // namespace
+
+extern "C" int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+                                 float* rstd, int M, int C, float eps, ocn_stream_t stream) {
+    OCN_CHECK_ARG(x && w && b && mean && rstd && (y_bf16 || y_f32), "ocn_layernorm_fwd: null operand");
+    OCN_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "ocn_layernorm_fwd: bad shape M=%d C=%d", M, C);
+    hipStream_t st = (hipStream_t)stream;
+    bf16* y16 = (bf16*)y_bf16;
+    switch (ocn_cdiv(C, 256)) {
+        case 1: launch_fwd<1>(st, x, w, b, y16, y_f32, mean, rstd, M, C, eps); break;
+        case 2: launch_fwd<2>(st, x, w, b, y16, y_f32, mean, rstd, M, C, eps); break;
+        case 3: launch_fwd<3>(st, x, w, b, y16, y_f32, mean, rstd, M, C, eps); break;
+        case 4: launch_fwd<4>(st, x, w, b, y16, y_f32, mean, rstd, M, C, eps); break;
+        case 5: launch_fwd<5>(st, x, w, b, y16, y_f32, mean, rstd, M, C, eps); break;
+        default: launch_fwd<8>(st, x, w, b, y16, y_f32, mean, rstd, M, C, eps); break;
+    }
+    OCN_CHECK_LAUNCH("ocn_layernorm_fwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
+                                 const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db,
+                                 int M, int C, ocn_stream_t stream) {
+    OCN_CHECK_ARG(dy && x && w && mean && rstd && dw && db && (dx_f32 || dx_bf16), "ocn_layernorm_bwd: null operand");
+    OCN_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "ocn_layernorm_bwd: bad shape M=%d C=%d", M, C);
+    hipStream_t st = (hipStream_t)stream;
+    bf16* dx16 = (bf16*)dx_bf16;
+    switch (ocn_cdiv(C, 256)) {
+        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+    }
+    OCN_CHECK_LAUNCH("ocn_layernorm_bwd");
+    return OCN_OK;
+}

@@ -1,0 +1,89 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) CLIP kernels.
+// wave = 64 lanes everywhere; MFMA = v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/openclip_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define OCN_LDS __attribute__((address_space(3)))
+#define OCN_GLB __attribute__((address_space(1)))
+#define OCN_DEV __device__ __forceinline__
+
+// ---- error plumbing (C ABI returns 0 / negative code; message via ocn_last_error) -------------
+void ocn_set_error(const char* fmt, ...);
+#define OCN_CHECK_ARG(cond, ...)        \
+    do {                                \
+        if (!(cond)) {                  \
+            ocn_set_error(__VA_ARGS__); \
+            return OCN_ERR_INVALID;     \
+        }                               \
+    } while (0)
+#define OCN_CHECK_LAUNCH(name)                                                      \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            ocn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return OCN_ERR_LAUNCH;                                                  \
+        }                                                                           \
+    } while (0)
+
+// ---- small device helpers ----------------------------------------------------------------------
+OCN_DEV float bf2f(bf16 v) { return (float)v; }
+OCN_DEV bf16 f2bf(float v) { return (bf16)v; }  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+
+OCN_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+OCN_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 16-byte async global -> LDS copy (LDS-DMA).  LDS destination = wave-uniform base + lane*16.
+OCN_DEV void glds16(const void* gptr, OCN_LDS void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const OCN_GLB void*)gptr, lds_wave_base, 16, 0, 0);
+}
+
+// LDS transposing read: within each 16-lane group, lane i passes the address of 4 contiguous bf16
+// = element [i>>2][(i&3)*4 .. +3] of a 4 x 16 block and receives column i: {blk[0][i] .. blk[3][i]}.
+OCN_DEV s16x4 lds_read_tr16(const OCN_LDS void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((OCN_LDS s16x4*)p);
+}
+
+OCN_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// row of accumulator register `reg` (0..15) of a 32x32 MFMA result for this lane; column = lane & 31
+OCN_DEV int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// exact-erf GELU and its derivative (nn.GELU(), reference transformer.py:295-299)
+OCN_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+OCN_DEV float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// bijective XCD-aware remap of a linear workgroup id: hardware places block b on XCD b % 8, so give
+// each XCD a contiguous chunk of the logical tile space (neighbouring tiles share operand panels in L2).
+OCN_DEV int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < nx) return bid;
+    const int xcd = bid % nx, idx = bid / nx;
+    const int q = nwg / nx, r = nwg % nx;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+static inline int ocn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,233 @@
+"""Contrastive losses of the hot path over the HIP kernels: drop-ins for ``open_clip.loss.ClipLoss`` and
+``SigLipLoss`` (reference ``src/open_clip/loss.py:57-141``, ``:314-489``) with the same constructor arguments,
+``forward`` signature and return convention, so ``CLIPTask(model, loss=NativeClipLoss(...))`` works
+(clip_task.py:26,38-39).
+
+Each loss is one autograd Function that computes the loss AND its feature / logit_scale gradients in the
+forward (the logit gradient G is a by-product of the same pass over the logits), so the backward is a scale by
+the incoming scalar.  Logits are bf16 x bf16 -> fp32 on MFMA (``ocn_gemm_nt``), statistics fp32.
+
+Distributed semantics reproduce ``gather_features`` (loss.py:29-54) exactly -- including which operands carry
+gradient in each (local_loss, gather_with_grad) mode -- with ONE packed all-gather of
+[B, 2E] per step instead of two, and a reduce-scatter in the backward when ``gather_with_grad``.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def _bf16_rows(x, kpad=None):
+    """fp32 [R,E] -> bf16 [R,E] (E % 64 == 0 for the hot configs; zero-pad K otherwise)"""
+    R, E = x.shape
+    Ep = _round_up(E, 64)
+    if Ep == E:
+        return ops.cast_bf16(x.contiguous())
+    out = torch.zeros(R, Ep, dtype=BF16, device=x.device)
+    out[:, :E].copy_(x)
+    return out
+
+
+def _bf16_transposed(x, npad):
+    """fp32 [N,E] -> bf16 [E, npad] with zero columns beyond N (K-operand of the G @ Y product)"""
+    N, E = x.shape
+    out = torch.zeros(E, npad, dtype=BF16, device=x.device)
+    if npad == N:
+        ops.cast_transpose_bf16(x.contiguous(), out)
+    else:
+        out[:, :N].copy_(ops.cast_transpose_bf16(x.contiguous()))
+    return out
+
+
+def _reduce_scatter_sum(out, inp):
+    """reduce-scatter(sum) of inp [W*B, X] into out [B, X]; RCCL does it natively, gloo (CPU tests) lacks the
+    collective, so fall back to all-reduce + slice there (same result)."""
+    if dist.get_backend() == "gloo":
+        tmp = inp.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        r, b = dist.get_rank(), out.shape[0]
+        out.copy_(tmp[r * b:(r + 1) * b])
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+
+
+class _PairTerm:
+    """One logits matrix  L = s * X @ Y^T (+ bias)  [R, N]  and what hangs off it."""
+
+    def __init__(self, X, Y, scale):
+        self.X, self.Y, self.s = X, Y, float(scale)
+        self.R, self.N, self.E = X.shape[0], Y.shape[0], X.shape[1]
+        self.x16, self.y16 = _bf16_rows(X), _bf16_rows(Y)
+        self.ldg = _round_up(self.N, 64)
+        self.logits = torch.empty(self.R, _round_up(self.N, 4), dtype=F32, device=X.device)[:, :self.N]
+        self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
+
+    def compute_logits(self, bias=None):
+        bvec = None if bias is None else torch.full((self.N,), float(bias), dtype=F32, device=self.X.device)
+        ops.gemm_nt(ops.EPI_F32, self.x16, self.y16, self.logits, bias=bvec, alpha=self.s)  # bias fused in the epilogue
+        return self
+
+    def softmax_ce(self, label_offset, loss_scale, grad_scale, acc):
+        """rows' CE against arange+offset -> acc[0] += loss, acc[1] += d/dscale; fills G"""
+        ops.softmax_ce_rows(self.logits, self.G, self.N, label_offset, loss_scale, grad_scale, 1.0 / self.s, acc[0:1], acc[1:2])
+
+    def siglip(self, label_offset, negative_only, bias, loss_scale, grad_scale, acc):
+        ops.siglip_rows(self.logits, self.G, self.N, label_offset, negative_only, bias, loss_scale, grad_scale, 1.0 / self.s,
+                        acc[0:1], acc[1:2], acc[2:3])
+
+    def dX(self):
+        """s * G @ Y  -> [R, E] fp32"""
+        yt = _bf16_transposed(self.Y, self.ldg)
+        out = torch.empty(self.R, self.E, dtype=F32, device=self.X.device)
+        return ops.gemm_nt(ops.EPI_F32, self.G, yt, out, alpha=self.s)
+
+    def dY(self):
+        """s * G^T @ X -> [N, E] fp32"""
+        Np = _round_up(self.N, 8)
+        Ep = self.x16.shape[1]
+        out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
+        ops.gemm_tn_accum(self.G[:, :Np], self.x16, out, alpha=self.s)
+        return out[:self.N, :self.E]
+
+
+class _ClipLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size):
+        I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
+        s = float(logit_scale.detach())
+        dev = I.device
+        B, E = I.shape
+        acc = torch.zeros(2, dtype=F32, device=dev)  # [loss_sum, dscale_sum]
+        if world_size > 1:
+            packed = torch.cat([I, T], dim=1)
+            allp = torch.empty(world_size * B, 2 * E, dtype=F32, device=dev)
+            dist.all_gather_into_tensor(allp, packed)
+            I_all, T_all = allp[:, :E].contiguous(), allp[:, E:].contiguous()
+        if world_size == 1:
+            # loss.py:109-110: li = s I T^T, lt = s T I^T ; labels arange(B)
+            ti = PairTerm(I, T, s).compute_logits()
+            tt = PairTerm(T, I, s).compute_logits()
+            for term in (ti, tt):
+                term.softmax_ce(0, 0.5 / B, 0.5 / B, acc)
+            dI = ti.dX() + tt.dY()
+            dT = tt.dX() + ti.dY()
+            d_all = None
+        elif local_loss:
+            # loss.py:103-104 + :82-83: li = s I_loc T_all^T, lt = s T_loc I_all^T, labels arange(B) + B*rank
+            ti = PairTerm(I, T_all, s).compute_logits()
+            tt = PairTerm(T, I_all, s).compute_logits()
+            for term in (ti, tt):
+                term.softmax_ce(B * rank, 0.5 / B, 0.5 / B, acc)
+            dI, dT = ti.dX(), tt.dX()            # through the local operands
+            d_all = None
+            if gather_with_grad:                  # ... and through the gathered ones (summed over ranks in backward)
+                d_all = torch.cat([tt.dY(), ti.dY()], dim=1).contiguous()  # [N, 2E]: d I_all | d T_all
+        else:
+            # loss.py:106-107: li = s I_all T_all^T, lt = li^T ; labels arange(N)
+            N = world_size * B
+            ti = PairTerm(I_all, T_all, s).compute_logits()
+            tt = PairTerm(T_all, I_all, s).compute_logits()
+            for term in (ti, tt):
+                term.softmax_ce(0, 0.5 / N, 0.5 / N, acc)
+            dI_all = ti.dX() + tt.dY()
+            dT_all = tt.dX() + ti.dY()
+            lo, hi = rank * B, (rank + 1) * B
+            if gather_with_grad:
+                dI = torch.zeros(B, E, dtype=F32, device=dev)
+                dT = torch.zeros(B, E, dtype=F32, device=dev)
+                d_all = torch.cat([dI_all, dT_all], dim=1).contiguous()
+            else:                                   # loss.py:47-50: only the local slot carries gradient
+                dI, dT = dI_all[lo:hi].contiguous(), dT_all[lo:hi].contiguous()
+                d_all = None
+        ctx.save_for_backward(dI, dT, acc, d_all)
+        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype)
+        return acc[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        dI, dT, acc, d_all = ctx.saved_tensors
+        world_size, B, E, idt, tdt = ctx.meta
+        if d_all is not None:  # backward of the differentiable all-gather = reduce-scatter(sum) (loss.py:23-26)
+            mine = torch.empty(B, 2 * E, dtype=F32, device=dI.device)
+            _reduce_scatter_sum(mine, d_all)
+            dI = dI + mine[:, :E]
+            dT = dT + mine[:, E:]
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None
+
+
+PairTerm = _PairTerm  # the one seam tests replace to exercise the collective plumbing on CPU/gloo
+
+
+class NativeClipLoss(nn.Module):
+    """``open_clip.loss.ClipLoss`` (loss.py:57-141) on the HIP path.  ``cache_labels`` is accepted for
+    signature parity; labels are an arange predicate inside the kernel (nothing to cache)."""
+
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1):
+        super().__init__()
+        self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
+        self.rank, self.world_size = rank, world_size
+
+    def forward(self, image_features, text_features, logit_scale, logit_bias=None, output_dict=False):
+        if logit_bias is not None:
+            raise NotImplementedError("NativeClipLoss: a logit_bias shifts every logit of a softmax row equally; use NativeSigLipLoss")
+        loss = _ClipLossFn.apply(image_features, text_features, logit_scale, self.local_loss, self.gather_with_grad,
+                                 self.rank, self.world_size)
+        return {"contrastive_loss": loss} if output_dict else loss
+
+
+class _SigLipLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size):
+        I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
+        s, b = float(logit_scale.detach()), float(logit_bias.detach())
+        dev = I.device
+        B, E = I.shape
+        acc = torch.zeros(3, dtype=F32, device=dev)  # loss, dscale, dbias
+        if world_size > 1:
+            T_all = torch.empty(world_size * B, E, dtype=F32, device=dev)
+            dist.all_gather_into_tensor(T_all, T)
+        else:
+            T_all = T
+        # loss.py:406-489: local chunk with positives on the diagonal, every other rank's chunk negative-only.
+        # One logits matrix [B, W*B]; the positive diagonal sits at column offset B*rank.
+        term = PairTerm(I, T_all, s).compute_logits(bias=b)
+        term.siglip(B * rank, 0, b, 1.0 / B, 1.0 / B, acc)
+        dI = term.dX()
+        dT_all = term.dY().contiguous()
+        ctx.save_for_backward(dI, dT_all, acc)
+        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype)
+        return acc[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        dI, dT_all, acc = ctx.saved_tensors
+        world_size, B, E, idt, tdt = ctx.meta
+        if world_size > 1:  # reverse of the neighbour exchange (loss.py:279-311): every chunk's grad returns to its owner
+            dT = torch.empty(B, E, dtype=F32, device=dI.device)
+            _reduce_scatter_sum(dT, dT_all)
+        else:
+            dT = dT_all
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None
+
+
+class NativeSigLipLoss(nn.Module):
+    """``open_clip.loss.SigLipLoss`` (loss.py:314-489).  The W-1 neighbour exchanges of 'bidir'/'shift' are
+    replaced by one all-gather of the text features (xGMI is fully connected; the payload is 2 MiB per rank)
+    and one reduce-scatter in the backward -- the loss value and every gradient are identical."""
+
+    def __init__(self, cache_labels=False, rank=0, world_size=1, dist_impl=None, chunk_size=0):
+        super().__init__()
+        self.cache_labels, self.rank, self.world_size = cache_labels, rank, world_size
+        self.dist_impl = dist_impl or "bidir"
+        self.chunk_size = chunk_size
+
+    def forward(self, image_features, text_features, logit_scale, logit_bias, output_dict=False):
+        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size)
+        return {"contrastive_loss": loss} if output_dict else loss

@@ -1,0 +1,458 @@
+"""Native CLIP model: the reference's ``CLIP`` object surface over the HIP hot path.
+
+``NativeCLIP`` keeps the reference's attribute names, parameter names/shapes and ``state_dict`` layout
+(reference ``src/open_clip/model.py:318-548``, ``transformer.py``) so that
+``open_clip.task.CLIPTask`` / ``open_clip_train.train.train_one_epoch`` drive it unmodified and reference
+checkpoints load with ``load_state_dict``.  Modules here are *parameter containers*; all arithmetic happens in
+``torch.autograd.Function``s that enqueue hand-written gfx950 kernels through the C ABI (``ops.py``).
+
+Precision policy (mirrors ``--precision amp_bf16``, precision.py:6-16): fp32 master weights, bf16 GEMM /
+attention operands with fp32 accumulation, fp32 residual stream, fp32 LayerNorm / softmax / loss statistics.
+Autograd granularity is one Function per residual block, so gradients reach ``.grad`` (and DDP's bucket hooks)
+block by block while the backward is still running, and block-granular recompute (``set_grad_checkpointing``)
+is a flag of the same Function.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .configs import get_model_config
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------------------
+# bf16 operand copies of fp32 master weights, refreshed when the parameter's version counter moves
+# ------------------------------------------------------------------------------------------------------
+class _WeightCache:
+    def __init__(self):
+        self._d = {}
+
+    def get(self, p: torch.Tensor, kind: str):
+        """kind: 'n' = bf16 copy [rows, cols]; 't' = bf16 transpose [cols, rows] (2-D views of p)"""
+        key = (p.data_ptr(), kind)
+        ver = p._version
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == ver and hit[1] == p.shape:
+            return hit[2]
+        w2 = p.detach().reshape(p.shape[0], -1)
+        out = ops.cast_bf16(w2) if kind == "n" else ops.cast_transpose_bf16(w2)
+        self._d[key] = (ver, p.shape, out)
+        return out
+
+    def clear(self):
+        self._d.clear()
+
+
+# ------------------------------------------------------------------------------------------------------
+# residual block (transformer.py:319-330)
+# ------------------------------------------------------------------------------------------------------
+def _block_forward(x, p, cache, B, L, heads, causal):
+    (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
+    M, C = x.shape
+    h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
+    qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
+    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, 64 ** -0.5)
+    xmid = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, cache.get(wo, "n"), ops.empty((M, C), F32, x), bias=bo, resid=x)
+    h2, _, mean2, rstd2 = ops.layernorm_fwd(xmid, ln2w, ln2b)
+    Fd = wfc.shape[0]
+    f = ops.empty((M, Fd), BF16, x)
+    g = ops.gemm_nt(ops.EPI_BIAS_GELU, h2, cache.get(wfc, "n"), ops.empty((M, Fd), BF16, x), bias=bfc, aux=f)
+    y = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g, cache.get(wproj, "n"), ops.empty((M, C), F32, x), bias=bproj, resid=xmid)
+    return y, (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g)
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, cache, B, L, heads, causal, recompute):
+        p = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj)
+        y, saved = _block_forward(x, p, cache, B, L, heads, causal)
+        ctx.meta = (cache, B, L, heads, causal, recompute)
+        if recompute:  # block-granular activation recompute (transformer.py:579-581): keep only the block input
+            ctx.save_for_backward(x, *p)
+        else:
+            ctx.save_for_backward(x, *p, *saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cache, B, L, heads, causal, recompute = ctx.meta
+        t = ctx.saved_tensors
+        x, p = t[0], t[1:13]
+        (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
+        if recompute:
+            _, saved = _block_forward(x, p, cache, B, L, heads, causal)
+        else:
+            saved = t[13:]
+        (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g) = saved
+        M, C = x.shape
+        Fd = wfc.shape[0]
+        dy = dy.contiguous()
+        # one zeroed fp32 arena for all of the block's parameter gradients (wgrad kernels accumulate atomically)
+        sizes = [q.numel() for q in p]
+        arena = torch.zeros(sum(sizes), dtype=F32, device=x.device)
+        grads, o = [], 0
+        for q, n in zip(p, sizes):
+            grads.append(arena[o:o + n].view(q.shape))
+            o += n
+        (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
+
+        dy16 = ops.cast_bf16(dy)
+        # ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid)))) ----
+        df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
+        ops.gemm_tn_accum(dy16, g, dwproj, dbproj)
+        dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
+        ops.gemm_tn_accum(df, h2, dwfc, dbfc)
+        dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
+        # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
+        da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
+        ops.gemm_tn_accum(dxmid16, a, dwo, dbo)
+        dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, 64 ** -0.5)
+        dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
+        ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv)
+        dx, _ = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=False)
+        return (dx, *grads, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------------
+# image embedding (transformer.py:793-808)
+# ------------------------------------------------------------------------------------------------------
+class _VisionEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, conv_w, cls, pos, lnw, lnb, cache, patch):
+        B, _, H, W = image.shape
+        width = conv_w.shape[0]
+        KP = 3 * patch * patch
+        Kpad = _round_up(KP, 64)
+        G = (H // patch) * (W // patch)
+        patches = ops.patchify(image.contiguous(), patch, Kpad)
+        if Kpad == KP:
+            w16 = cache.get(conv_w, "n")
+        else:  # zero-padded K (patch 14: 588 -> 640); rare path, weight-sized
+            w16 = torch.zeros(width, Kpad, dtype=BF16, device=image.device)
+            w16[:, :KP].copy_(cache.get(conv_w, "n"))
+        po = ops.gemm_nt(ops.EPI_F32, patches, w16, ops.empty((B * G, width), F32, patches))
+        emb = ops.embed_assemble_fwd(po, cls, pos, B, G, width)
+        _, x0, mean, rstd = ops.layernorm_fwd(emb, lnw, lnb, want_bf16=False, want_f32=True)
+        ctx.save_for_backward(patches, emb, mean, rstd, lnw, conv_w, cls, pos)
+        ctx.meta = (B, G, width, KP, Kpad)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        patches, emb, mean, rstd, lnw, conv_w, cls, pos = ctx.saved_tensors
+        B, G, width, KP, Kpad = ctx.meta
+        dev = emb.device
+        dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
+        demb, _ = ops.layernorm_bwd(dx0.contiguous(), emb, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
+        dpos, dcls = torch.zeros_like(pos), torch.zeros_like(cls)
+        dpatch = ops.embed_assemble_bwd(demb, dpos, dcls, B, G, width)
+        dw = torch.zeros(width, Kpad, dtype=F32, device=dev)
+        ops.gemm_tn_accum(dpatch, patches, dw)
+        dconv = (dw if Kpad == KP else dw[:, :KP].contiguous()).view(conv_w.shape)
+        return None, dconv, dcls, dpos, dlnw, dlnb, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# text embedding (model.py:399-401)
+# ------------------------------------------------------------------------------------------------------
+class _TextEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, text, table, pos):
+        x = ops.token_embed_fwd(text.contiguous(), table, pos)
+        ctx.save_for_backward(text, table, pos)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        text, table, pos = ctx.saved_tensors
+        dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
+        ops.token_embed_bwd(text.contiguous(), dx.contiguous(), dtable, dpos)
+        return None, dtable, dpos
+
+
+# ------------------------------------------------------------------------------------------------------
+# pooled head: LN on the pooled token only (== LN on all tokens then pool), projection, F.normalize
+#   vision: transformer.py:829-831 + :923 ; text: model.py:403-411 + transformer.py:941-944
+# ------------------------------------------------------------------------------------------------------
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lnw, lnb, proj, idx, cache, B, L, normalize):
+        pooled = ops.gather_rows(x, idx, B, L)
+        p16, _, mean, rstd = ops.layernorm_fwd(pooled, lnw, lnb)
+        E = proj.shape[1]
+        feat = ops.gemm_nt(ops.EPI_F32, p16, cache.get(proj, "t"), ops.empty((B, E), F32, x))
+        if normalize:
+            y, _, inv = ops.l2norm_fwd(feat)
+        else:
+            y, inv = feat, None
+        ctx.save_for_backward(pooled, p16, mean, rstd, lnw, proj, idx, y, inv)
+        ctx.meta = (cache, B, L, normalize, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pooled, p16, mean, rstd, lnw, proj, idx, y, inv = ctx.saved_tensors
+        cache, B, L, normalize, xshape = ctx.meta
+        dy = dy.contiguous().float()
+        dfeat = ops.l2norm_bwd(dy, y, inv) if normalize else dy
+        dfeat16 = ops.cast_bf16(dfeat)
+        C, E = proj.shape
+        dp16 = ops.gemm_nt(ops.EPI_BF16, dfeat16, cache.get(proj, "n"), ops.empty((B, C), BF16, dy))
+        dproj = torch.zeros_like(proj)
+        ops.gemm_tn_accum(p16, dfeat16, dproj)
+        dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
+        dpooled, _ = ops.layernorm_bwd(dp16, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
+        dx = torch.zeros(xshape, dtype=F32, device=dy.device)
+        ops.scatter_rows(dpooled, idx, dx, B, L)
+        return dx, dlnw, dlnb, dproj, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameter containers with the reference's names
+# ------------------------------------------------------------------------------------------------------
+class _Params(nn.Module):
+    """Holds parameters only; calling it is a bug (the arithmetic lives in the autograd Functions)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} is a parameter container of the native path; it has no forward")
+
+
+class LayerNorm(_Params):  # layers.py:20-26
+    def __init__(self, width):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(width))
+        self.bias = nn.Parameter(torch.zeros(width))
+        self.eps = 1e-5
+        self.normalized_shape = (width,)
+
+
+class Linear(_Params):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        bound = 1 / math.sqrt(in_features)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+
+
+class Attention(_Params):  # transformer.py:61-155 (fused in_proj, out_proj)
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads, self.head_dim, self.scale = num_heads, dim // num_heads, (dim // num_heads) ** -0.5
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim))
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim))
+        self.out_proj = Linear(dim, dim)
+
+
+class Mlp(_Params):  # transformer.py:295-299 (OrderedDict c_fc / gelu / c_proj)
+    def __init__(self, width, mlp_width):
+        super().__init__()
+        self.c_fc = Linear(width, mlp_width)
+        self.c_proj = Linear(mlp_width, width)
+
+
+class ResidualAttentionBlock(nn.Module):  # transformer.py:274-330
+    def __init__(self, d_model, n_head, mlp_ratio=4.0):
+        super().__init__()
+        self.ln_1 = LayerNorm(d_model)
+        self.attn = Attention(d_model, n_head)
+        self.ln_2 = LayerNorm(d_model)
+        self.mlp = Mlp(d_model, int(d_model * mlp_ratio))
+        self.n_head = n_head
+
+    def params(self):
+        return (self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight, self.attn.in_proj_bias,
+                self.attn.out_proj.weight, self.attn.out_proj.bias, self.ln_2.weight, self.ln_2.bias,
+                self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias)
+
+    def get_weight_dtype(self):
+        return self.mlp.c_fc.weight.dtype
+
+    def forward(self, x, cache, B, L, causal, recompute=False):
+        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute)
+
+
+class Transformer(nn.Module):  # transformer.py:476-585
+    def __init__(self, width, layers, heads, mlp_ratio=4.0):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads, mlp_ratio) for _ in range(layers)])
+        self.grad_checkpointing = False
+
+    def get_cast_dtype(self):  # transformer.py:537-538
+        return self.resblocks[0].get_weight_dtype()
+
+    def set_grad_checkpointing(self, enable=True, impl="inline"):
+        self.grad_checkpointing = enable
+
+    def forward(self, x, cache, B, L, causal):
+        rc = self.grad_checkpointing and torch.is_grad_enabled()
+        for r in self.resblocks:
+            x = r(x, cache, B, L, causal, rc)
+        return x
+
+
+class _Conv1(_Params):
+    def __init__(self, width, patch):
+        super().__init__()
+        bound = 1 / math.sqrt(3 * patch * patch)
+        self.weight = nn.Parameter(torch.empty(width, 3, patch, patch).uniform_(-bound, bound))
+
+
+class _Embedding(_Params):
+    def __init__(self, vocab, width):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(vocab, width).normal_(std=0.02))
+        self.num_embeddings, self.embedding_dim = vocab, width
+
+
+class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: learnable pos, 'tok' pool, no patch dropout)
+    def __init__(self, image_size, patch_size, width, layers, heads, mlp_ratio, output_dim):
+        super().__init__()
+        self.image_size = (image_size, image_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (image_size // patch_size, image_size // patch_size)
+        self.output_dim = output_dim
+        self.width = width
+        scale = width ** -0.5
+        self.conv1 = _Conv1(width, patch_size)
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn(self.grid_size[0] * self.grid_size[1] + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads, mlp_ratio)
+        self.ln_post = LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self._cache = _WeightCache()
+
+    def set_grad_checkpointing(self, enable=True, impl="inline"):
+        self.transformer.set_grad_checkpointing(enable, impl)
+
+    def no_weight_decay(self):  # transformer.py:745-751
+        return {"positional_embedding", "class_embedding"}
+
+    def lock(self, unlocked_groups=0, freeze_bn_stats=False):  # transformer.py:753-781 (whole-tower lock only)
+        assert unlocked_groups == 0, "partial unlocking is not supported by the native tower"
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, image, normalize=False):
+        B = image.shape[0]
+        if image.shape[2] != self.image_size[0] or image.shape[3] != self.image_size[1]:
+            raise RuntimeError(f"image size {tuple(image.shape[2:])} != {self.image_size}")
+        T = self.grid_size[0] * self.grid_size[1] + 1
+        x = _VisionEmbedFn.apply(image, self.conv1.weight, self.class_embedding, self.positional_embedding,
+                                 self.ln_pre.weight, self.ln_pre.bias, self._cache, self.patch_size[0])
+        x = self.transformer(x, self._cache, B, T, False)
+        return _HeadFn.apply(x, self.ln_post.weight, self.ln_post.bias, self.proj, None, self._cache, B, T, normalize)
+
+
+class NativeCLIP(nn.Module):
+    """Drop-in for ``open_clip.model.CLIP`` (model.py:318-548) on the ViT + causal-text path."""
+
+    def __init__(self, embed_dim, vision_cfg, text_cfg, init_logit_scale=math.log(1 / 0.07), init_logit_bias=None,
+                 output_dict=False, **_ignored):
+        super().__init__()
+        v, t = dict(vision_cfg), dict(text_cfg)
+        self.output_dict = output_dict
+        self.embed_dim = embed_dim
+        head_width = v.get("head_width", 64)
+        if head_width != 64 or t["width"] // t["heads"] != 64:
+            raise NotImplementedError("the native attention kernels support head_dim 64 only (ViT-B/L towers)")
+        self.visual = VisionTransformer(v["image_size"], v["patch_size"], v["width"], v["layers"], v["width"] // head_width,
+                                        v.get("mlp_ratio", 4.0), embed_dim)
+        tw = t["width"]
+        self.transformer = Transformer(tw, t["layers"], t["heads"], t.get("mlp_ratio", 4.0))
+        self.context_length = t["context_length"]
+        self.vocab_size = t["vocab_size"]
+        self.token_embedding = _Embedding(self.vocab_size, tw)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, tw).normal_(std=0.01))
+        self.ln_final = LayerNorm(tw)
+        self.text_projection = nn.Parameter(torch.empty(tw, embed_dim).normal_(std=tw ** -0.5))
+        self.text_pool_type = "argmax"
+        self.text_eos_id = None
+        mask = torch.full((self.context_length, self.context_length), float("-inf")).triu_(1)
+        self.register_buffer("attn_mask", mask, persistent=False)  # model.py:360 (kept for API parity; kernels use a predicate)
+        self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
+        self.logit_bias = nn.Parameter(torch.ones([]) * init_logit_bias) if init_logit_bias is not None else None
+        self._cache = _WeightCache()
+
+    # ---- reference API surface (model.py:369-411) ----
+    def lock_image_tower(self, unlocked_groups=0, freeze_bn_stats=False):
+        self.visual.lock(unlocked_groups=unlocked_groups, freeze_bn_stats=freeze_bn_stats)
+
+    def lock_text_tower(self, unlocked_layers: int = 0, freeze_layer_norm: bool = True, pooler_in_head: bool = True):
+        assert unlocked_layers == 0, "partial unlocking is not supported by the native tower"
+        for n, p in self.named_parameters():
+            if not n.startswith("visual.") and n not in ("logit_scale", "logit_bias"):
+                p.requires_grad = False
+
+    def set_grad_checkpointing(self, enable=True, impl="inline"):
+        self.visual.set_grad_checkpointing(enable, impl)
+        self.transformer.set_grad_checkpointing(enable, impl)
+
+    def no_weight_decay(self):
+        return {"positional_embedding"} | {"visual." + n for n in self.visual.no_weight_decay()}
+
+    def encode_image(self, image, normalize: bool = False):
+        return self.visual(image, normalize)
+
+    def encode_text(self, text, normalize: bool = False):
+        B, L = text.shape
+        if L != self.context_length:
+            raise RuntimeError(f"text length {L} != context_length {self.context_length}")
+        x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
+        x = self.transformer(x, self._cache, B, L, True)
+        idx = ops.argmax_rows(text.contiguous())
+        return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, idx, self._cache, B, L, normalize)
+
+    def get_logits(self, image, text):
+        i, t = self.encode_image(image, True), self.encode_text(text, True)
+        li = self.logit_scale.exp() * i @ t.T
+        if self.logit_bias is not None:
+            li = li + self.logit_bias
+        return li, li.T
+
+    def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):
+        image_features = self.encode_image(image, normalize=True) if image is not None else None
+        text_features = self.encode_text(text, normalize=True) if text is not None else None
+        if self.output_dict:
+            out = {"image_features": image_features, "text_features": text_features, "logit_scale": self.logit_scale.exp()}
+            if self.logit_bias is not None:
+                out["logit_bias"] = self.logit_bias.clone()
+            return out
+        if self.logit_bias is not None:
+            return image_features, text_features, self.logit_scale.exp(), self.logit_bias.clone()
+        return image_features, text_features, self.logit_scale.exp()
+
+
+def create_model(model_name: str, pretrained: Optional[str] = None, precision: str = "amp_bf16", device="cuda",
+                 output_dict: Optional[bool] = None, init_logit_scale=None, init_logit_bias=None, **model_kwargs):
+    """Counterpart of ``open_clip.factory.create_model`` (factory.py:264-287) for the native path.
+    ``pretrained`` may be a local ``.pt`` state-dict path (no hub access); ``precision`` must be an
+    amp_bf16-equivalent mode (the kernels implement exactly that policy)."""
+    if precision not in ("amp_bf16", "amp_bfloat16", "bf16", "fp32"):
+        raise ValueError(f"precision {precision!r} not supported by the native path (implements amp_bf16 semantics)")
+    cfg = get_model_config(model_name)
+    for k, val in model_kwargs.items():
+        cfg[k] = val
+    kw = {}
+    if init_logit_scale is not None:
+        kw["init_logit_scale"] = init_logit_scale
+    if init_logit_bias is not None:
+        kw["init_logit_bias"] = init_logit_bias
+    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=bool(output_dict), **kw)
+    if pretrained:
+        sd = torch.load(pretrained, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        model.load_state_dict(sd, strict=True)
+    return model.to(device)

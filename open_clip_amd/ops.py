@@ -1,0 +1,232 @@
+"""Tensor-level wrappers over the C ABI (include/openclip_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream.  Every wrapper checks
+device / dtype / contiguity, then enqueues the HIP kernel on ``torch.cuda.current_stream()``.  There is no
+CPU or ATen fallback: a CPU tensor or a missing library raises.
+"""
+import torch
+
+from . import _lib
+
+EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID_F32, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise RuntimeError(f"open_clip_amd: '{name}' must live on the MI355X (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"open_clip_amd: '{name}' must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"open_clip_amd: '{name}' must be contiguous")
+    return t.data_ptr()
+
+
+def _chk2d(t, dtype, name):
+    """2-D, unit inner stride, arbitrary row stride -> (ptr, ld)"""
+    if not t.is_cuda:
+        raise RuntimeError(f"open_clip_amd: '{name}' must live on the MI355X (got {t.device}); there is no CPU path")
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"open_clip_amd: '{name}' must be a 2-D {dtype} matrix with unit inner stride")
+    return t.data_ptr(), t.stride(0)
+
+
+def empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ---- GEMMs ------------------------------------------------------------------------------------------
+def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
+    """out[M,N] = a[M,K] @ b[N,K]^T (+ epilogue); a, b bf16; out bf16 or fp32 depending on ``epi``."""
+    pa, lda = _chk2d(a, BF16, "a")
+    pb, ldb = _chk2d(b, BF16, "b")
+    odt = F32 if epi in (EPI_BIAS_RESID_F32, EPI_F32) else BF16
+    po, ldc = _chk2d(out, odt, "out")
+    M, K = a.shape
+    N = b.shape[0]
+    if b.shape[1] != K or out.shape[0] != M or out.shape[1] != N:
+        raise RuntimeError(f"gemm_nt: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)}")
+    if resid is not None and (resid.shape != out.shape or resid.stride(0) != ldc):
+        raise RuntimeError("gemm_nt: resid must match out")
+    if aux is not None and (aux.shape != out.shape or aux.stride(0) != ldc):
+        raise RuntimeError("gemm_nt: aux must match out")
+    _lib.call("ocn_gemm_nt", epi, pa, lda, pb, ldb, po, ldc, M, N, K, _chk(bias, F32, "bias"),
+              0 if resid is None else _chk2d(resid, F32, "resid")[0], 0 if aux is None else _chk2d(aux, BF16, "aux")[0],
+              float(alpha), _stream())
+    return out
+
+
+def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0):
+    """dw[N,K] += alpha * a[M,N]^T @ b[M,K]; dbias[N] += alpha * colsum(a).  a, b bf16; dw, dbias fp32."""
+    pa, lda = _chk2d(a, BF16, "a")
+    pb, ldb = _chk2d(b, BF16, "b")
+    pw, ldw = _chk2d(dw, F32, "dw")
+    M, N = a.shape
+    K = b.shape[1]
+    if b.shape[0] != M or dw.shape[0] != N or dw.shape[1] != K:
+        raise RuntimeError(f"gemm_tn_accum: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} dw{tuple(dw.shape)}")
+    _lib.call("ocn_gemm_tn_accum", pa, lda, pb, ldb, pw, ldw, M, N, K, _chk(dbias, F32, "dbias"), float(alpha), _stream())
+    return dw
+
+
+# ---- casts --------------------------------------------------------------------------------------------
+def cast_bf16(src, out=None):
+    out = empty(src.shape, BF16, src) if out is None else out
+    _lib.call("ocn_cast_f32_bf16", _chk(src, F32, "src"), _chk(out, BF16, "out"), src.numel(), _stream())
+    return out
+
+
+def cast_transpose_bf16(src, out=None):
+    R, C = src.shape
+    out = empty((C, R), BF16, src) if out is None else out
+    _lib.call("ocn_cast_transpose_f32_bf16", _chk(src, F32, "src"), _chk(out, BF16, "out"), R, C, _stream())
+    return out
+
+
+# ---- LayerNorm -----------------------------------------------------------------------------------------
+def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
+    M, C = x.shape
+    y16 = empty((M, C), BF16, x) if want_bf16 else None
+    y32 = empty((M, C), F32, x) if want_f32 else None
+    mean, rstd = empty((M,), F32, x), empty((M,), F32, x)
+    _lib.call("ocn_layernorm_fwd", _chk(x, F32, "x"), _chk(w, F32, "w"), _chk(b, F32, "b"), _chk(y16, BF16, "y16"),
+              _chk(y32, F32, "y32"), _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), M, C, float(eps), _stream())
+    return y16, y32, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False):
+    M, C = x.shape
+    is32 = dy.dtype == F32
+    dx32 = empty((M, C), F32, x) if want_f32 else None
+    dx16 = empty((M, C), BF16, x) if want_bf16 else None
+    _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
+              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(dx32, F32, "dx32"),
+              _chk(dx16, BF16, "dx16"), _chk(dw, F32, "dw"), _chk(db, F32, "db"), M, C, _stream())
+    return dx32, dx16
+
+
+# ---- attention -------------------------------------------------------------------------------------------
+def attn_fwd(qkv, B, L, H, causal, scale):
+    C = H * 64
+    if qkv.shape != (B * L, 3 * C):
+        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(B * L, 3 * C)} (head_dim must be 64)")
+    out = empty((B * L, C), BF16, qkv)
+    lse = empty((B * H * L,), F32, qkv)
+    _lib.call("ocn_attn_fwd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), B, L, H, int(causal),
+              float(scale), _stream())
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale):
+    dqkv = empty(qkv.shape, BF16, qkv)
+    _lib.call("ocn_attn_bwd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
+              _chk(dqkv, BF16, "dqkv"), B, L, H, int(causal), float(scale), _stream())
+    return dqkv
+
+
+# ---- embeddings / pooling ----------------------------------------------------------------------------------
+def patchify(image, P, Kpad):
+    B, Cin, H, W = image.shape
+    if Cin != 3:
+        raise RuntimeError("patchify: images must have 3 channels")
+    is16 = image.dtype == BF16
+    out = empty((B * (H // P) * (W // P), Kpad), BF16, image)
+    _lib.call("ocn_patchify", _chk(image, BF16 if is16 else F32, "image"), int(is16), _chk(out, BF16, "patches"), B, H, W, P, Kpad, _stream())
+    return out
+
+
+def embed_assemble_fwd(patch_out, cls, pos, B, G, C):
+    emb = empty((B * (G + 1), C), F32, patch_out)
+    _lib.call("ocn_embed_assemble_fwd", _chk(patch_out, F32, "patch_out"), _chk(cls, F32, "cls"), _chk(pos, F32, "pos"),
+              _chk(emb, F32, "emb"), B, G, C, _stream())
+    return emb
+
+
+def embed_assemble_bwd(demb, dpos, dcls, B, G, C):
+    dpatch = empty((B * G, C), BF16, demb)
+    _lib.call("ocn_embed_assemble_bwd", _chk(demb, F32, "demb"), _chk(dpatch, BF16, "dpatch"), _chk(dpos, F32, "dpos"),
+              _chk(dcls, F32, "dcls"), B, G, C, _stream())
+    return dpatch
+
+
+def token_embed_fwd(text, table, pos):
+    B, L = text.shape
+    vocab, C = table.shape
+    x = empty((B * L, C), F32, table)
+    _lib.call("ocn_token_embed_fwd", _chk(text, torch.int64, "text"), _chk(table, F32, "table"), _chk(pos, F32, "pos"),
+              _chk(x, F32, "x"), B, L, C, vocab, _stream())
+    return x
+
+
+def token_embed_bwd(text, dx, dtable, dpos):
+    B, L = text.shape
+    vocab, C = dtable.shape
+    _lib.call("ocn_token_embed_bwd", _chk(text, torch.int64, "text"), _chk(dx, F32, "dx"), _chk(dtable, F32, "dtable"),
+              _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
+
+
+def argmax_rows(text):
+    B, L = text.shape
+    idx = empty((B,), torch.int32, text)
+    _lib.call("ocn_argmax_rows", _chk(text, torch.int64, "text"), _chk(idx, torch.int32, "idx"), B, L, _stream())
+    return idx
+
+
+def gather_rows(x, idx, B, L):
+    C = x.shape[1]
+    out = empty((B, C), F32, x)
+    _lib.call("ocn_gather_rows", _chk(x, F32, "x"), _chk(idx, torch.int32, "idx"), _chk(out, F32, "out"), B, L, C, _stream())
+    return out
+
+
+def scatter_rows(d, idx, dx, B, L):
+    C = d.shape[1]
+    _lib.call("ocn_scatter_rows", _chk(d, F32, "d"), _chk(idx, torch.int32, "idx"), _chk(dx, F32, "dx"), 0, B, L, C, _stream())
+    return dx
+
+
+def l2norm_fwd(x, eps=1e-12):
+    B, E = x.shape
+    y, y16, inv = empty((B, E), F32, x), empty((B, E), BF16, x), empty((B,), F32, x)
+    _lib.call("ocn_l2norm_fwd", _chk(x, F32, "x"), _chk(y, F32, "y"), _chk(y16, BF16, "y16"), _chk(inv, F32, "inv"), B, E, float(eps), _stream())
+    return y, y16, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    B, E = y.shape
+    dx = empty((B, E), F32, y)
+    _lib.call("ocn_l2norm_bwd", _chk(dy, F32, "dy"), _chk(y, F32, "y"), _chk(inv, F32, "inv"), _chk(dx, F32, "dx"), B, E, _stream())
+    return dx
+
+
+# ---- losses ---------------------------------------------------------------------------------------------------
+def softmax_ce_rows(logits, G, N, label_offset, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum):
+    pl, ld = _chk2d(logits, F32, "logits")
+    pg, ldg = _chk2d(G, BF16, "G")
+    _lib.call("ocn_softmax_ce_rows", pl, ld, pg, ldg, logits.shape[0], N, int(label_offset), float(loss_scale), float(grad_scale),
+              float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _stream())
+
+
+def siglip_rows(logits, G, N, label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum):
+    pl, ld = _chk2d(logits, F32, "logits")
+    pg, ldg = _chk2d(G, BF16, "G")
+    _lib.call("ocn_siglip_rows", pl, ld, pg, ldg, logits.shape[0], N, int(label_offset), int(negative_only), float(bias),
+              float(loss_scale), float(grad_scale), float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"),
+              _chk(dscale_sum, F32, "dscale_sum"), _chk(dbias_sum, F32, "dbias_sum"), _stream())
+
+
+# ---- optimizer ----------------------------------------------------------------------------------------------------
+def sumsq_accum(x, out):
+    _lib.call("ocn_sumsq_accum", _chk(x, F32, "x"), x.numel(), _chk(out, F32, "out"), _stream())
+
+
+def adamw_step(w, g, m, v, lr, beta1, beta2, eps, weight_decay, step, w_bf16=None, clip_coef=None):
+    _lib.call("ocn_adamw_step", _chk(w, F32, "w"), _chk(g, F32, "g"), _chk(m, F32, "m"), _chk(v, F32, "v"),
+              _chk(w_bf16, BF16, "w_bf16"), w.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+              int(step), _chk(clip_coef, F32, "clip_coef"), _stream())

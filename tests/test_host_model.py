@@ -1,0 +1,90 @@
+"""CPU: host-side mirror of the reference interface (names, shapes, state-dict layout, API surface) and the
+'no fallback' rule.  Compute is never executed here."""
+import numpy as np
+import pytest
+import torch
+
+from open_clip_amd.configs import count_params, get_model_config
+from open_clip_amd.model import NativeCLIP, create_model
+from open_clip_amd.synth import init_state_dict, synthetic_batch
+from tests.golden_util import load
+
+
+def _tiny(**kw):
+    cfg = get_model_config("tiny-test")
+    return NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], **kw), cfg
+
+
+def test_state_dict_layout_matches_reference_fixture():
+    """keys/shapes == what the reference's CLIP produced (fixture written by oracle/make_golden.py)"""
+    g = load("tiny_clip.npz")
+    ref = {k[2:]: tuple(v.shape) for k, v in g.items() if k.startswith("w/")}
+    model, _ = _tiny()
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref
+    assert "attn_mask" not in mine and model.attn_mask.shape == (16, 16)  # non-persistent buffer (model.py:360)
+    names = [n for n, _ in model.named_parameters()]
+    assert sorted(names) == sorted(ref)
+
+
+def test_vitb32_parameter_count_and_keys():
+    cfg = get_model_config("ViT-B-32")
+    sd = init_state_dict(cfg, 0)
+    assert len(sd) == 302
+    assert sum(v.numel() for v in sd.values()) == 151277313 == count_params(cfg)
+    with torch.device("meta"):
+        m = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def test_load_state_dict_roundtrip_and_siglip_bias():
+    model, cfg = _tiny(init_logit_bias=-10.0, init_logit_scale=float(np.log(10)))
+    sd = init_state_dict(cfg, 3, perturb=True, siglip=True)
+    model.load_state_dict(sd, strict=True)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert model.logit_bias is not None and model.logit_scale.ndim == 0
+
+
+def test_reference_api_surface():
+    model, cfg = _tiny(output_dict=True)
+    assert model.no_weight_decay() == {"positional_embedding", "visual.positional_embedding", "visual.class_embedding"}
+    assert model.visual.image_size == (64, 64) and model.visual.grid_size == (2, 2)
+    assert model.context_length == 16 and model.vocab_size == 512 and model.embed_dim == 64
+    assert model.transformer.get_cast_dtype() == torch.float32
+    model.set_grad_checkpointing(True)
+    assert model.visual.transformer.grad_checkpointing and model.transformer.grad_checkpointing
+    model.lock_image_tower()
+    assert not any(p.requires_grad for p in model.visual.parameters())
+    assert model.logit_scale.requires_grad and model.text_projection.requires_grad
+    for blk in model.transformer.resblocks:  # discoverable block type (FSDP shard units, base_task.py:245-254)
+        assert type(blk).__name__ == "ResidualAttentionBlock"
+
+
+def test_forward_on_cpu_fails_loudly():
+    model, cfg = _tiny(output_dict=True)
+    batch = synthetic_batch(cfg, 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(image=batch["image"], text=batch["text"])
+    from open_clip_amd.loss import NativeClipLoss
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        NativeClipLoss()(torch.randn(4, 64), torch.randn(4, 64), torch.tensor(10.0))
+
+
+def test_create_model_rejects_unsupported():
+    with pytest.raises(RuntimeError, match="not found"):
+        create_model("RN50", device="cpu")
+    with pytest.raises(NotImplementedError, match="head_dim 64"):
+        create_model("ViT-H-14", device="meta")
+    with pytest.raises(ValueError, match="precision"):
+        create_model("tiny-test", precision="fp16", device="cpu")
+
+
+def test_synthetic_batch_layout():
+    cfg = get_model_config("ViT-B-32")
+    b = synthetic_batch(cfg, 16, seed=1234)
+    t = b["text"]
+    assert t.shape == (16, 77) and t.dtype == torch.int64 and b["image"].shape == (16, 3, 224, 224)
+    assert (t[:, 0] == 49406).all() and ((t == 49407).sum(-1) == 1).all()
+    eot = t.argmax(-1)
+    assert (eot >= 8).all() and all((t[i, eot[i] + 1:] == 0).all() for i in range(16))

@@ -1,0 +1,338 @@
+"""Per-kernel parity tests on a real MI355X: every C-ABI entry point against a plain fp32 torch statement of the
+same op on the same (bf16-rounded) inputs.  Tolerances are written next to each check:
+  * fp32 outputs of bf16-operand GEMMs: rel-L2 <= 2e-5 (accumulation order only)
+  * bf16 outputs: |err| <= 2^-8 * |ref| + tiny abs (one bf16 rounding)
+  * atomically accumulated fp32 reductions: rel-L2 <= 1e-4
+A human-readable report with the measured errors is appended to gpurun_out/parity_report.txt.
+"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.txt")
+
+
+def _report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+    print(line)
+
+
+def rel_l2(got, ref):
+    got, ref = got.double().flatten(), ref.double().flatten()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def check(name, got, ref, rel=None, bf16_out=False, abs_tol=0.0):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    r = rel_l2(got, ref)
+    mx = float((got - ref).abs().max())
+    _report(f"{name:46s} rel_l2={r:.3e} max_abs={mx:.3e} ref_max={float(ref.abs().max()):.3e}")
+    if bf16_out:
+        bound = ref.abs() * 2.0 ** -7 + abs_tol + 1e-6 * float(ref.abs().max())
+        bad = ((got - ref).abs() > bound).sum().item()
+        assert bad == 0, f"{name}: {bad} elements beyond the bf16 rounding bound (rel_l2={r:.3e}, max_abs={mx:.3e})"
+    if rel is not None:
+        assert r <= rel, f"{name}: rel_l2 {r:.3e} > {rel:.1e}"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from open_clip_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_probe_mfma_layout(dev):
+    from open_clip_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    a = bf(torch.randn(32, 16, generator=g)).to(dev)
+    b = bf(torch.randn(32, 16, generator=g)).to(dev)  # [n, k]: asymmetric so a transposed C would be caught
+    c = torch.zeros(32, 32, device=dev)
+    _lib.call("ocn_probe_mfma32", a.data_ptr(), b.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    check("probe_mfma32 C=A.B^T", c, a.float() @ b.float().t(), rel=1e-6)
+
+
+def test_probe_tr16_layout(dev):
+    from open_clip_amd import _lib
+    src = torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32)
+    inp = bf(src).to(dev)  # values < 512 are exact in bf16
+    out = torch.zeros(64, 4, dtype=torch.bfloat16, device=dev)
+    _lib.call("ocn_probe_tr16", inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    exp = torch.zeros(64, 4)
+    for lane in range(64):
+        i, g, h = lane & 15, (lane >> 4) & 1, lane >> 5
+        for j in range(4):
+            exp[lane, j] = src[h * 8 + j, g * 16 + i]
+    got = out.float().cpu()
+    if not torch.equal(got, exp):
+        _report("probe_tr16 MISMATCH; raw lane table (lane: 4 values):")
+        for lane in range(64):
+            _report(f"  lane {lane:2d}: {got[lane].tolist()}  expected {exp[lane].tolist()}")
+    assert torch.equal(got, exp)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (400, 384, 192), (1000, 2304, 768), (77 * 8, 512, 2048), (37, 6, 64), (4096, 4096, 512)])
+def test_gemm_nt_epilogues(dev, M, N, K):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = bf(torch.randn(M, K, generator=g)).to(dev)
+    b = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = torch.randn(M, N, generator=g).to(dev)
+    ref = a.float() @ b.float().t()
+    tag = f"gemm_nt[{M}x{N}x{K}]"
+    out = ops.gemm_nt(ops.EPI_F32, a, b, torch.empty(M, N, device=dev), bias=bias, alpha=0.5)
+    check(tag + " f32", out, 0.5 * ref + bias, rel=2e-5)
+    out = ops.gemm_nt(ops.EPI_BF16, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=bias)
+    check(tag + " bf16+bias", out, ref + bias, bf16_out=True)
+    out = ops.gemm_nt(ops.EPI_BF16, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev))
+    check(tag + " bf16", out, ref, bf16_out=True)
+    out = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, b, torch.empty(M, N, device=dev), bias=bias, resid=resid)
+    check(tag + " resid", out, ref + bias + resid, rel=2e-5)
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    out = ops.gemm_nt(ops.EPI_BIAS_GELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=bias, aux=aux)
+    pre = ref + bias
+    check(tag + " gelu.pre", aux, pre, bf16_out=True)
+    check(tag + " gelu.out", out, torch.nn.functional.gelu(pre), bf16_out=True, abs_tol=1e-3)
+    fpre = bf(torch.randn(M, N, generator=g)).to(dev)
+    out = ops.gemm_nt(ops.EPI_DGELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), aux=fpre)
+    x = fpre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(torch.ones_like(x))
+    check(tag + " dgelu", out, ref * x.grad, bf16_out=True, abs_tol=1e-3)
+
+
+def test_gemm_nt_strided_views(dev):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(5)
+    abig = bf(torch.randn(300, 256, generator=g)).to(dev)
+    a = abig[:, 64:192]  # lda 256, K 128
+    b = bf(torch.randn(96, 128, generator=g)).to(dev)
+    obig = torch.zeros(300, 128, device=dev)
+    out = obig[:, :96]
+    ops.gemm_nt(ops.EPI_F32, a, b, out)
+    check("gemm_nt strided", out, a.float() @ b.float().t(), rel=2e-5)
+    assert float(obig[:, 96:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (400, 384, 128), (1000, 768, 2304), (5000, 64, 136), (33, 8, 8), (8 * 77, 1536, 512)])
+def test_gemm_tn_accum(dev, M, N, K):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, N, generator=g)).to(dev)
+    b = bf(torch.randn(M, K, generator=g)).to(dev)
+    base = torch.randn(N, K, generator=g).to(dev)
+    dw = base.clone()
+    db = torch.zeros(N, device=dev)
+    ops.gemm_tn_accum(a, b, dw, db, alpha=0.25)
+    check(f"gemm_tn[{M}x{N}x{K}] dW", dw, base + 0.25 * (a.float().t() @ b.float()), rel=1e-4)
+    check(f"gemm_tn[{M}x{N}x{K}] dbias", db, 0.25 * a.float().sum(0), rel=1e-4)
+
+
+def test_cast_and_transpose(dev):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(300, 130, generator=g).to(dev)
+    assert torch.equal(ops.cast_bf16(w), w.to(torch.bfloat16))
+    assert torch.equal(ops.cast_transpose_bf16(w), w.t().contiguous().to(torch.bfloat16))
+    v = torch.randn(1027, generator=g).to(dev)
+    assert torch.equal(ops.cast_bf16(v), v.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C", [(37, 128), (400, 768), (616, 512), (257, 1024), (100, 1280), (5, 192)])
+def test_layernorm(dev, M, C):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(M * C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    b = (0.1 * torch.randn(C, generator=g)).to(dev)
+    y16, y32, mean, rstd = ops.layernorm_fwd(x, w, b, want_bf16=True, want_f32=True)
+    ref = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5)
+    check(f"ln_fwd[{M}x{C}] f32", y32, ref, rel=2e-6)
+    check(f"ln_fwd[{M}x{C}] bf16", y16, ref, bf16_out=True)
+    check(f"ln_fwd[{M}x{C}] mean", mean, x.mean(-1), rel=1e-5)
+    for dy_dtype in (torch.bfloat16, torch.float32):
+        dy = torch.randn(M, C, generator=g).to(dev).to(dy_dtype)
+        dres = torch.randn(M, C, generator=g).to(dev)
+        xr = x.clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5).backward(dy.float())
+        dw, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx32, dx16 = ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=dres, want_f32=True, want_bf16=True)
+        check(f"ln_bwd[{M}x{C},{dy_dtype}] dx", dx32, xr.grad + dres, rel=1e-5)
+        check(f"ln_bwd[{M}x{C},{dy_dtype}] dx16", dx16, xr.grad + dres, bf16_out=True)
+        check(f"ln_bwd[{M}x{C},{dy_dtype}] dw", dw, wr.grad, rel=1e-4)
+        check(f"ln_bwd[{M}x{C},{dy_dtype}] db", db, br.grad, rel=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, L, H, causal):
+    C = H * 64
+    q, k, v = qkv.float().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=qkv.device).triu_(1)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * L, C)
+    lse = torch.logsumexp(s, dim=-1)  # [B,H,L]
+    return o, lse.reshape(-1)
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, False), (2, 77, 3, True), (5, 5, 2, False), (2, 16, 2, True), (1, 257, 2, False), (4, 128, 1, True)])
+def test_attention(dev, B, L, H, causal):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(B * L + H)
+    C = H * 64
+    qkv = bf(torch.randn(B * L, 3 * C, generator=g) * 1.5).to(dev)
+    out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125)
+    x = qkv.float().requires_grad_(True)
+    ref, ref_lse = _attn_ref(x, B, L, H, causal)
+    tag = f"attn[B{B} L{L} H{H} c{int(causal)}]"
+    check(tag + " out", out, ref.detach(), rel=6e-3)       # P is rounded to bf16 before P.V
+    check(tag + " lse", lse, ref_lse.detach(), rel=1e-5)
+    dout = bf(torch.randn(B * L, C, generator=g)).to(dev)
+    ref.backward(dout.float())
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, B, L, H, causal, 0.125)
+    check(tag + " dqkv", dqkv, x.grad, rel=1.5e-2)          # P, dS rounded to bf16; delta from bf16 O
+    for i, nm in enumerate("qkv"):
+        check(tag + f" d{nm}", dqkv[:, i * C:(i + 1) * C], x.grad[:, i * C:(i + 1) * C], rel=2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,P,width", [(3, 64, 32, 128), (2, 224, 32, 768), (2, 28, 14, 128)])
+def test_vision_embed_kernels(dev, B, H, P, width):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    img = torch.randn(B, 3, H, H, generator=g).to(dev)
+    KP = 3 * P * P
+    Kpad = (KP + 63) // 64 * 64
+    G = (H // P) ** 2
+    patches = ops.patchify(img, P, Kpad)
+    ref = torch.nn.functional.unfold(img, P, stride=P).transpose(1, 2).reshape(B * G, KP)
+    assert torch.equal(patches[:, :KP], ref.to(torch.bfloat16))
+    assert float(patches[:, KP:].float().abs().sum()) == 0.0
+    po = torch.randn(B * G, width, generator=g).to(dev)
+    cls, pos = torch.randn(width, generator=g).to(dev), torch.randn(G + 1, width, generator=g).to(dev)
+    emb = ops.embed_assemble_fwd(po, cls, pos, B, G, width)
+    ref = torch.cat([cls.expand(B, 1, width), po.reshape(B, G, width)], 1) + pos
+    assert torch.equal(emb, ref.reshape(B * (G + 1), width))
+    demb = torch.randn(B * (G + 1), width, generator=g).to(dev)
+    dpos, dcls = torch.zeros_like(pos), torch.zeros_like(cls)
+    dpatch = ops.embed_assemble_bwd(demb, dpos, dcls, B, G, width)
+    d3 = demb.reshape(B, G + 1, width)
+    check("embed_bwd dpos", dpos, d3.sum(0), rel=1e-5)
+    check("embed_bwd dcls", dcls, d3[:, 0].sum(0), rel=1e-5)
+    assert torch.equal(dpatch, d3[:, 1:].reshape(B * G, width).to(torch.bfloat16))
+
+
+def test_text_embed_and_pool_kernels(dev):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, L, C, V = 37, 77, 192, 1000
+    text = torch.randint(0, V, (B, L), generator=g)
+    text[:, 5] = V - 1
+    text[3, 2] = V - 1  # tie: the first index must win
+    text = text.to(dev)
+    table, pos = torch.randn(V, C, generator=g).to(dev), torch.randn(L, C, generator=g).to(dev)
+    x = ops.token_embed_fwd(text, table, pos)
+    assert torch.equal(x, (table[text] + pos).reshape(B * L, C))
+    idx = ops.argmax_rows(text)
+    assert torch.equal(idx.long(), text.argmax(-1))
+    dx = torch.randn(B * L, C, generator=g).to(dev)
+    dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
+    ops.token_embed_bwd(text, dx, dtable, dpos)
+    ref = torch.zeros_like(table).index_add_(0, text.reshape(-1), dx)
+    check("token_embed_bwd dtable", dtable, ref, rel=1e-5)
+    check("token_embed_bwd dpos", dpos, dx.reshape(B, L, C).sum(0), rel=1e-5)
+    pooled = ops.gather_rows(x, idx, B, L)
+    assert torch.equal(pooled, x.reshape(B, L, C)[torch.arange(B), idx.long()])
+    assert torch.equal(ops.gather_rows(x, None, B, L), x.reshape(B, L, C)[:, 0])
+    dfull = torch.zeros(B * L, C, device=dev)
+    ops.scatter_rows(pooled, idx, dfull, B, L)
+    assert torch.equal(dfull.reshape(B, L, C)[torch.arange(B), idx.long()], pooled) and float(dfull.abs().sum()) == float(pooled.abs().sum())
+    y, y16, inv = ops.l2norm_fwd(pooled)
+    check("l2norm_fwd", y, torch.nn.functional.normalize(pooled, dim=-1), rel=1e-6)
+    pr = pooled.clone().requires_grad_(True)
+    dy = torch.randn(B, C, generator=g).to(dev)
+    torch.nn.functional.normalize(pr, dim=-1).backward(dy)
+    check("l2norm_bwd", ops.l2norm_bwd(dy, y, inv), pr.grad, rel=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,N,off", [(6, 6, 0), (64, 200, 64), (300, 300, 0)])
+def test_loss_row_kernels(dev, R, N, off):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(R + N)
+    logits = (torch.randn(R, N, generator=g) * 4).to(dev)
+    ldg = (N + 63) // 64 * 64
+    G = torch.zeros(R, ldg, dtype=torch.bfloat16, device=dev)
+    acc = torch.zeros(2, device=dev)
+    s = 14.3
+    ops.softmax_ce_rows(logits, G, N, off, 0.5 / R, 0.5 / R, 1.0 / s, acc[0:1], acc[1:2])
+    lr = logits.clone().requires_grad_(True)
+    labels = torch.arange(R, device=dev) + off
+    loss = 0.5 * torch.nn.functional.cross_entropy(lr, labels)
+    loss.backward()
+    check(f"ce_rows[{R}x{N}] loss", acc[0:1], loss.detach().reshape(1), rel=1e-5)
+    check(f"ce_rows[{R}x{N}] G", G[:, :N], lr.grad, rel=4e-3)
+    check(f"ce_rows[{R}x{N}] dscale", acc[1:2], ((lr.grad * logits).sum() / s).reshape(1), rel=1e-4)
+    for neg in (0, 1):
+        G.zero_()
+        acc3 = torch.zeros(3, device=dev)
+        bias = -3.0
+        ops.siglip_rows(logits, G, N, off, neg, bias, 1.0 / R, 1.0 / R, 1.0 / s, acc3[0:1], acc3[1:2], acc3[2:3])
+        lr = logits.clone().requires_grad_(True)
+        lab = -torch.ones(R, N, device=dev)
+        if not neg:
+            lab[torch.arange(R), labels] = 1.0
+        loss = -torch.nn.functional.logsigmoid(lab * lr).sum() / R
+        loss.backward()
+        check(f"siglip_rows[{R}x{N},neg{neg}] loss", acc3[0:1], loss.detach().reshape(1), rel=1e-5)
+        check(f"siglip_rows[{R}x{N},neg{neg}] G", G[:, :N], lr.grad, rel=4e-3)
+        check(f"siglip_rows[{R}x{N},neg{neg}] dscale", acc3[1:2], ((lr.grad * (logits - bias)).sum() / s).reshape(1), rel=1e-4)
+        check(f"siglip_rows[{R}x{N},neg{neg}] dbias", acc3[2:3], lr.grad.sum().reshape(1), rel=1e-4)
+
+
+def test_adamw_and_sumsq(dev):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(2)
+    n = 100003
+    w0, gr = torch.randn(n, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.AdamW([p], lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2)
+    w, m, v = w0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    w16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    for step in (1, 2, 3):
+        p.grad = gr.clone()
+        opt.step()
+        ops.adamw_step(w, gr, m, v, 5e-4, 0.9, 0.98, 1e-6, 0.2, step, w_bf16=w16)
+    check("adamw 3 steps", w, p.detach(), rel=1e-6)
+    assert torch.equal(w16, w.to(torch.bfloat16))
+    out = torch.zeros(1, device=dev)
+    ops.sumsq_accum(gr, out)
+    check("sumsq", out, (gr.double() ** 2).sum().float().reshape(1), rel=1e-5)
+
+
+def test_ops_fail_loudly_on_cpu_tensors(dev):
+    from open_clip_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.cast_bf16(torch.randn(8))
+    with pytest.raises(RuntimeError, match="K=.*multiple of 64"):
+        a = torch.zeros(8, 32, dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(ops.EPI_F32, a, a, torch.zeros(8, 8, device=dev))
