@@ -69,8 +69,8 @@ def test_probe_mfma_layout(dev):
 
 def test_probe_tr16_layout(dev):
     from open_clip_amd import _lib
-    src = torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32)
-    inp = bf(src).to(dev)  # values < 512 are exact in bf16
+    src = bf(torch.arange(16 * 32, dtype=torch.float32).reshape(16, 32)).float()  # compare against the bf16-rounded table
+    inp = bf(src).to(dev)
     out = torch.zeros(64, 4, dtype=torch.bfloat16, device=dev)
     _lib.call("ocn_probe_tr16", inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     exp = torch.zeros(64, 4)
