@@ -57,6 +57,10 @@ int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, vo
 int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
                       float* dbias, float alpha, ocn_stream_t stream);
 
+/* tuning hook: force the NT tile geometry (0 = auto, 1 = 128x128/4 waves, 2 = 256x256/8 waves, 3 = 256x128/8 waves).
+ * Process-global; used by tools/gemm_bench.py and the tests to cover every geometry. */
+int ocn_set_gemm_variant(int nt_variant);
+
 /* ---- casts -------------------------------------------------------------------------------------
  * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */
 int ocn_cast_f32_bf16(const float* src, void* dst, int64_t n, ocn_stream_t stream);

@@ -41,11 +41,12 @@ struct GemmNtArgs {
     int tiles_n, ntiles;
 };
 
-// rows [row0, row0+128) x k [k0, k0+64) of a row-major bf16 matrix -> LDS tile (rows clamped)
+// rows [row0, row0+ROWS) x k [k0, k0+64) of a row-major bf16 matrix -> LDS tile (rows clamped), NW waves
+template <int ROWS, int NW>
 OCN_DEV void stage_nt(const bf16* __restrict__ G, int ld, int row0, int nrows, int k0, char* sT, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int seg = wave * 4 + j;  // 8 rows per wave-instruction
+    for (int j = 0; j < ROWS / 8 / NW; ++j) {
+        const int seg = wave + j * NW;  // 8 rows per wave-instruction
         const int r = seg * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz_nt(r);
         int gr = row0 + r;
@@ -102,81 +103,92 @@ OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+// Geometry: workgroup tile BM x BN, WR x WC waves, each wave (BM/WR) x (BN/WC) = TI x TJ blocks of 32x32.
+//   <128,128,2,2>: 4 waves, 64 KiB ring, 2 workgroups / CU (small problems, ragged edges)
+//   <256,256,2,4>: 8 waves, 128 KiB ring, 1 workgroup / CU, wave tile 128x64 (less LDS traffic per MFMA)
+template <int EPI, int BM_, int BN_, int WR, int WC>
+__global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 * ((BM_ + BN_) * 256 <= 65536 ? 2 : 1)) / 256)
+void gemm_nt_kernel(GemmNtArgs a) {
+    constexpr int NW = WR * WC;
+    constexpr int TI = BM_ / WR / 32, TJ = BN_ / WC / 32;
+    constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = xcd_remap(blockIdx.x, a.ntiles);
-    const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = (tile / a.tiles_n) * BM_, n0 = (tile % a.tiles_n) * BN_;
+    const int wm = wave / WC, wn = wave % WC;
     const int lr = lane & 31, lh = lane >> 5;
     const int sw = swz_nt(lr);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_row = (wm * 64 + lr) * 128, b_row = (wn * 64 + lr) * 128;
+    const int a_row = (wm * TI * 32 + lr) * 128, b_row = (wn * TJ * 32 + lr) * 128;
     const int nk = a.K / BK;
 
-    stage_nt(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-    stage_nt(a.B, a.ldb, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_nt<BM_, NW>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+    stage_nt<BN_, NW>(a.B, a.ldb, n0, a.N, 0, smem + A_BYTES, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE_BYTES;
+        char* cur = smem + (kt & 1) * STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMA pieces of tile kt have landed
         __syncthreads();                                  // everyone's have; everyone is done with tile kt-1
         if (kt + 1 < nk) {
-            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            stage_nt(a.A, a.lda, m0, a.M, (kt + 1) * BK, nxt, wave, lane);
-            stage_nt(a.B, a.ldb, n0, a.N, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            stage_nt<BM_, NW>(a.A, a.lda, m0, a.M, (kt + 1) * BK, nxt, wave, lane);
+            stage_nt<BN_, NW>(a.B, a.ldb, n0, a.N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
         }
         const char* sA = cur;
-        const char* sB = cur + TILE_BYTES;
+        const char* sB = cur + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int cpos = ((s * 2 + lh) ^ sw) << 4;
-            bf16x8 af[2], bq[2];
+            bf16x8 af[TI], bq[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(sA + a_row + i * 32 * 128 + cpos);
+            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(sA + a_row + i * 32 * 128 + cpos);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bq[j] = *(const bf16x8*)(sB + b_row + j * 32 * 128 + cpos);
+            for (int j = 0; j < TJ; ++j) bq[j] = *(const bf16x8*)(sB + b_row + j * 32 * 128 + cpos);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bq[j], acc[i][j]);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bq[j], acc[i][j]);
         }
     }
     __syncthreads();  // all waves finished reading the ring; reuse it as per-wave C staging
 
-    // stage the wave's 64x64 fp32 sub-tile through its private 16 KiB so that global traffic is whole rows
-    float* sC = (float*)(smem + wave * 16384);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sC[(i * 32 + mfma32_row(r, lane)) * 64 + j * 32 + lr] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): own LDS writes visible to own reads
+    // stage 32 x (TJ*32) fp32 slabs of the wave's sub-tile through its private LDS region so that global
+    // traffic is whole rows (full 128-/256-byte lines) for every epilogue operand
+    constexpr int TW = TJ * 32;                      // columns of the wave tile
+    float* sC = (float*)(smem + wave * (32 * TW * 4));  // <= 8 KiB per wave
     const bool vec_ok = ((a.N & 3) == 0) && ((a.ldc & 3) == 0);
-    const int col = (lane & 15) * 4;
-    const int gn = n0 + wn * 64 + col;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const int gm = m0 + wm * 64 + row;
-        const f32x4 v = *(const f32x4*)(sC + row * 64 + col);
-        if (gm < a.M) {
-            if (vec_ok) {
-                if (gn < a.N) epilogue_store4<EPI>(a, gm, gn, v);
-            } else {
+    constexpr int LPR = TW / 4;                      // lanes per row (16 for TW=64)
+    constexpr int RPI = 64 / LPR;                    // rows per iteration
+    const int col = (lane % LPR) * 4;
+    const int gn = n0 + wn * TW + col;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (gn + e < a.N) epilogue_store1<EPI>(a, gm, gn + e, v[e]);
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sC[mfma32_row(r, lane) * TW + j * 32 + lr] = acc[i][j][r];
+#pragma unroll 4
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR;
+            const int gm = m0 + (wm * TI + i) * 32 + row;
+            const f32x4 v = *(const f32x4*)(sC + row * TW + col);
+            if (gm < a.M) {
+                if (vec_ok) {
+                    if (gn < a.N) epilogue_store4<EPI>(a, gm, gn, v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gn + e < a.N) epilogue_store1<EPI>(a, gm, gn + e, v[e]);
+                }
             }
         }
     }
@@ -306,11 +318,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
     }
 }
 
-template <int EPI>
-int launch_nt(const GemmNtArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(a.ntiles), dim3(256), 0, st, a);
+template <int EPI, int BM_, int BN_, int WR, int WC>
+int launch_nt_geo(GemmNtArgs a, hipStream_t st) {
+    constexpr int LDS = 2 * (BM_ + BN_) * 128;
+    a.tiles_n = ocn_cdiv(a.N, BN_);
+    a.ntiles = ocn_cdiv(a.M, BM_) * a.tiles_n;
+    auto kern = gemm_nt_kernel<EPI, BM_, BN_, WR, WC>;
+    if (LDS > 65536) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(WR * WC * 64), LDS, st, a);
     OCN_CHECK_LAUNCH("ocn_gemm_nt");
     return OCN_OK;
+}
+
+int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128
+
+template <int EPI>
+int launch_nt(const GemmNtArgs& a, hipStream_t st) {
+    int v = g_nt_variant;
+    if (v == 0) v = (a.M >= 2048 && a.N >= 256) ? 2 : 1;
+    if (v == 2) return launch_nt_geo<EPI, 256, 256, 2, 4>(a, st);
+    if (v == 3) return launch_nt_geo<EPI, 256, 128, 4, 2>(a, st);
+    return launch_nt_geo<EPI, 128, 128, 2, 2>(a, st);
 }
 
 }  // namespace
@@ -328,8 +362,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (bf16*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    a.tiles_n = ocn_cdiv(N, BN);
-    a.ntiles = ocn_cdiv(M, BM) * a.tiles_n;
+    a.tiles_n = 0; a.ntiles = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OCN_EPI_BF16: return launch_nt<OCN_EPI_BF16>(a, st);
@@ -340,6 +373,11 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     }
     ocn_set_error("ocn_gemm_nt: unknown epilogue %d", epilogue);
     return OCN_ERR_INVALID;
+}
+
+extern "C" int ocn_set_gemm_variant(int nt_variant) {
+    g_nt_variant = nt_variant;
+    return OCN_OK;
 }
 
 extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,

@@ -67,12 +67,29 @@ OCN_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mf
 // row of accumulator register `reg` (0..15) of a 32x32 MFMA result for this lane; column = lane & 31
 OCN_DEV int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// exact-erf GELU and its derivative (nn.GELU(), reference transformer.py:295-299)
-OCN_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (nn.GELU(), reference transformer.py:295-299) and its derivative.  erf by Abramowitz-Stegun
+// 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 resolution of the stored result) so the GEMM epilogues
+// stay off the VALU critical path: one v_exp_f32 + one v_rcp_f32 + 6 FMAs, shared between cdf and pdf.
+OCN_DEV void gelu_parts(float x, float& cdf, float& e) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);  // exp(-x^2/2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = p * t * e;               // 1 - erf(|u|)
+    cdf = x >= 0.f ? 1.0f - 0.5f * q : 0.5f * q;
+}
+OCN_DEV float gelu_f(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 OCN_DEV float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
 // bijective XCD-aware remap of a linear workgroup id: hardware places block b on XCD b % 8, so give
