@@ -45,7 +45,7 @@ int ocn_version(void);
  * ocn_gemm_nt: C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  Replaces F.linear
  *   (transformer.py:169 in_proj, :246 out_proj, :295-299 c_fc + nn.GELU + c_proj), the residual adds of
  *   transformer.py:328-329, `pooled @ proj` (:923), `x @ text_projection` (model.py:409), the logit
- *   matmul (loss.py:103-110) and every dgrad of the backward (a17).  K % 64 == 0; A, B bf16 row-major.
+ *   matmul (loss.py:103-110) and every dgrad of the backward (a17).  K % 32 == 0; A, B bf16 row-major.
  *   bias [N] fp32 or NULL; resid fp32 [M,ldc] (EPI 2); aux bf16 [M,ldc] (EPI 1: written, EPI 3: read). */
 int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* out, int ldc, int M, int N, int K,
                 const float* bias, const float* resid, void* aux, float alpha, ocn_stream_t stream);
@@ -57,8 +57,10 @@ int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, vo
 int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
                       float* dbias, float alpha, ocn_stream_t stream);
 
-/* tuning hook: force the NT tile geometry (0 = auto, 1 = 128x128/4 waves, 2 = 256x256/8 waves, 3 = 256x128/8 waves).
- * Process-global; used by tools/gemm_bench.py and the tests to cover every geometry. */
+/* tuning hook (process-global; tools/gemm_bench.py and the tests use it to cover every kernel):
+ *   bits 0..3  NT kernel: 0 auto, 1 128x128 two-stage, 2 256x256 two-stage, 3 256x128 two-stage, 4 256x256 4-stage ring
+ *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
+ *   bits 8..   developer ablation mask of the ring kernel (timing experiments only; results are wrong) */
 int ocn_set_gemm_variant(int nt_variant);
 
 /* ---- casts -------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ struct GemmNtArgs {
     int lda, ldb, ldc, M, N, K;
     float alpha;
     int tiles_n, ntiles;
+    int ablate;  // developer ablation mask (tools/gemm_bench.py): 1 = no in-loop DMA, 2 = no in-loop barrier
 };
 
 // rows [row0, row0+ROWS) x k [k0, k0+64) of a row-major bf16 matrix -> LDS tile (rows clamped), NW waves
@@ -195,6 +196,228 @@ void gemm_nt_kernel(GemmNtArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT "ring" kernel: 256x256 tile, 8 waves (2x4, wave tile 128x64), BK = 32, 4-stage LDS ring (4 x 32 KiB),
+// LDS-DMA prefetch three K-steps ahead with COUNTED vmcnt (never drained in the main loop), one raw
+// s_barrier per K-step.  Epilogue operands (residual / saved pre-activation) are prefetched into registers
+// one 32-row slab ahead so the epilogue is bandwidth- not latency-bound.
+// LDS rows are 64 B (32 bf16): 4 chunks of 16 B, chunk ^= (row>>2)&3 (conflict-free ds_read_b128 fragments).
+// ------------------------------------------------------------------------------------------------
+OCN_DEV int swz64(int r) { return (r >> 2) & 3; }
+
+template <int ROWS>
+OCN_DEV void stage_ring(const bf16* __restrict__ G, int ld, int row0, int nrows, int k0, char* sT, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < ROWS / 16 / 8; ++j) {
+        const int seg = wave + j * 8;  // 16 rows (x 64 B) per wave-instruction
+        const int r = seg * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ swz64(r);
+        int gr = row0 + r;
+        gr = gr < nrows ? gr : nrows - 1;
+        glds16(G + (size_t)gr * ld + k0 + c * 8, (OCN_LDS void*)(sT + seg * 1024));
+    }
+}
+
+template <int EPI>
+struct EpiBuf {
+    f32x4 r[8];  // residual (EPI 2) or pre-activation as floats (EPI 3) for the 8 row-iterations of a slab
+};
+
+// unconditional (address-clamped) loads: straight-line code lets the compiler keep counted vmcnt waits
+template <int EPI>
+OCN_DEV void epi_prefetch(const GemmNtArgs& a, int gm_base, int gn, int lane, EpiBuf<EPI>& b) {
+    if (EPI != OCN_EPI_BIAS_RESID_F32 && EPI != OCN_EPI_DGELU) return;
+    const int gnc = gn < a.N ? gn : a.N - 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        int gm = gm_base + it * 4 + (lane >> 4);
+        gm = gm < a.M ? gm : a.M - 1;
+        const size_t o = (size_t)gm * a.ldc + gnc;
+        if (EPI == OCN_EPI_BIAS_RESID_F32) {
+            b.r[it] = *(const f32x4*)(a.resid + o);
+        } else {
+            const bf16x4 p4 = *(const bf16x4*)(a.aux + o);
+            b.r[it] = (f32x4){bf2f(p4[0]), bf2f(p4[1]), bf2f(p4[2]), bf2f(p4[3])};
+        }
+    }
+}
+
+template <int EPI>
+OCN_DEV void epi_apply_store(const GemmNtArgs& a, int gm, int gn, f32x4 v, f32x4 bias, f32x4 extra) {
+    const size_t o = (size_t)gm * a.ldc + gn;
+    if (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_F32) v = v * a.alpha + bias; else v = v + bias;
+    if (EPI == OCN_EPI_BF16) {
+        bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *(bf16x4*)((bf16*)a.out + o) = o4;
+    } else if (EPI == OCN_EPI_BIAS_GELU) {
+        bf16x4 p4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *(bf16x4*)(a.aux + o) = p4;
+        bf16x4 o4 = {f2bf(gelu_f(v[0])), f2bf(gelu_f(v[1])), f2bf(gelu_f(v[2])), f2bf(gelu_f(v[3]))};
+        *(bf16x4*)((bf16*)a.out + o) = o4;
+    } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
+        *(f32x4*)((float*)a.out + o) = v + extra;
+    } else if (EPI == OCN_EPI_DGELU) {
+        bf16x4 o4 = {f2bf(v[0] * dgelu_f(extra[0])), f2bf(v[1] * dgelu_f(extra[1])), f2bf(v[2] * dgelu_f(extra[2])),
+                     f2bf(v[3] * dgelu_f(extra[3]))};
+        *(bf16x4*)((bf16*)a.out + o) = o4;
+    } else {
+        *(f32x4*)((float*)a.out + o) = v;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs a) {
+    constexpr int RBM = 256, RBN = 256, RBK = 32, NSTAGE = 4;
+    constexpr int A_BYTES = RBM * 64, STAGE = (RBM + RBN) * 64;  // 32 KiB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE * STAGE = 128 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const int m0 = (tile / a.tiles_n) * RBM, n0 = (tile % a.tiles_n) * RBN;
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, wave tile 128 x 64
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nk = a.K / RBK;
+
+    // per-lane DMA source pointers (advance by one K-step = 64 bytes); wave w moves rows [16w,16w+16) and
+    // [128+16w, ...) of the A tile and the same of the B tile: 4 LDS-DMA instructions per stage per wave
+    const bf16* pa[2];
+    const bf16* pb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + j * 8) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ swz64(r);
+        int ga = m0 + r, gb = n0 + r;
+        ga = ga < a.M ? ga : a.M - 1;
+        gb = gb < a.N ? gb : a.N - 1;
+        pa[j] = a.A + (size_t)ga * a.lda + c * 8;
+        pb[j] = a.B + (size_t)gb * a.ldb + c * 8;
+    }
+#define OCN_DMA_A(J, SLOT) glds16(pa[J], (OCN_LDS void*)(smem + (SLOT) * STAGE + (wave + (J) * 8) * 1024)); pa[J] += RBK;
+#define OCN_DMA_B(J, SLOT) glds16(pb[J], (OCN_LDS void*)(smem + (SLOT) * STAGE + A_BYTES + (wave + (J) * 8) * 1024)); pb[J] += RBK;
+    // issue the first three stages, then the first epilogue slab's operands (older loads retire first)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < nk) {
+            OCN_DMA_A(0, s) OCN_DMA_A(1, s) OCN_DMA_B(0, s) OCN_DMA_B(1, s)
+        }
+    }
+    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldc & 3) == 0);
+    const int col = (lane & 15) * 4;
+    const int gn = n0 + wn * 64 + col;
+    const int gm_wave = m0 + wm * 128;
+    EpiBuf<EPI> ebuf;
+    if (vec_ok) epi_prefetch<EPI>(a, gm_wave, gn, lane, ebuf);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_row = (wm * 128 + lr) * 64, b_row = (wn * 64 + lr) * 64;
+    const int sw = swz64(lr);
+    const int cpos0 = ((0 + lh) ^ sw) << 4, cpos1 = ((2 + lh) ^ sw) << 4;  // k-substeps 0 / 1 of a stage
+    bf16x8 a0[4], b0[2], a1[4], b1[2];
+#define OCN_LOAD_FRAGS(AF, BF, STG, CPOS)                                                        \
+    {                                                                                            \
+        const char* sA_ = smem + ((STG)&3) * STAGE;                                              \
+        const char* sB_ = sA_ + A_BYTES;                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = *(const bf16x8*)(sA_ + a_row + i * 32 * 64 + (CPOS)); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) BF[j] = *(const bf16x8*)(sB_ + b_row + j * 32 * 64 + (CPOS)); \
+    }
+#define OCN_MFMA_BLOCK(AF, BF)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(AF[i], BF[j], acc[i][j]);
+
+    // stage 0 must be visible before the first fragment read
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    OCN_LOAD_FRAGS(a0, b0, 0, cpos0);
+    // One K-step.  Fragments of (kt, k-substep 0) are already in registers.  Make stage kt+1 visible (its first
+    // fragments are fetched at the end of the step); stage kt+2 may stay in flight (4 DMA ops per stage per wave).
+    // The 4 DMA issues of stage kt+3 are spread between the first MFMAs so that they sit in the shadow of queued
+    // matrix work instead of in front of it.  DMA / WAIT4 are compile-time so the body is branch-free.
+#define OCN_RING_STEP(DMA, WAIT4)                                                                  \
+    {                                                                                              \
+        if (WAIT4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        if (!(a.ablate & 2)) __builtin_amdgcn_s_barrier();                                         \
+        const int slot = (kt + 3) & 3;                                                             \
+        OCN_LOAD_FRAGS(a1, b1, kt, cpos1);                                                         \
+        acc[0][0] = mfma32(a0[0], b0[0], acc[0][0]);                                               \
+        acc[0][1] = mfma32(a0[0], b0[1], acc[0][1]);                                               \
+        if (DMA) { OCN_DMA_A(0, slot) }                                                            \
+        acc[1][0] = mfma32(a0[1], b0[0], acc[1][0]);                                               \
+        acc[1][1] = mfma32(a0[1], b0[1], acc[1][1]);                                               \
+        if (DMA) { OCN_DMA_A(1, slot) }                                                            \
+        acc[2][0] = mfma32(a0[2], b0[0], acc[2][0]);                                               \
+        acc[2][1] = mfma32(a0[2], b0[1], acc[2][1]);                                               \
+        if (DMA) { OCN_DMA_B(0, slot) }                                                            \
+        acc[3][0] = mfma32(a0[3], b0[0], acc[3][0]);                                               \
+        acc[3][1] = mfma32(a0[3], b0[1], acc[3][1]);                                               \
+        if (DMA) { OCN_DMA_B(1, slot) }                                                            \
+        const int nstg = kt + 1 < nk ? kt + 1 : kt;                                                \
+        OCN_LOAD_FRAGS(a0, b0, nstg, cpos0);                                                       \
+        OCN_MFMA_BLOCK(a1, b1);                                                                    \
+    }
+    int kt = 0;
+    if (!(a.ablate & 1)) {
+        for (; kt + 3 < nk; ++kt) OCN_RING_STEP(true, true)
+    }
+    for (; kt + 2 < nk; ++kt) OCN_RING_STEP(false, true)
+    for (; kt < nk; ++kt) OCN_RING_STEP(false, false)
+#undef OCN_RING_STEP
+#undef OCN_LOAD_FRAGS
+#undef OCN_MFMA_BLOCK
+#undef OCN_DMA_A
+#undef OCN_DMA_B
+    __builtin_amdgcn_s_barrier();  // all waves finished reading the ring; reuse it as per-wave C staging
+
+    float* sC = (float*)(smem + wave * 8192);  // 32 rows x 64 cols fp32 per wave
+    if (vec_ok) {
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias && gn < a.N) bias4 = *(const f32x4*)(a.bias + gn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sC[mfma32_row(r, lane) * 64 + j * 32 + lr] = acc[i][j][r];
+            EpiBuf<EPI> cur = ebuf;
+            if (i + 1 < 4) epi_prefetch<EPI>(a, gm_wave + (i + 1) * 32, gn, lane, ebuf);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const int gm = gm_wave + i * 32 + row;
+                const f32x4 v = *(const f32x4*)(sC + row * 64 + col);
+                if (gm < a.M && gn < a.N) epi_apply_store<EPI>(a, gm, gn, v, bias4, cur.r[it]);
+            }
+        }
+    } else {  // ragged N / unaligned ldc: scalar stores (tests and tiny heads only)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sC[mfma32_row(r, lane) * 64 + j * 32 + lr] = acc[i][j][r];
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const int gm = gm_wave + i * 32 + row;
+                const f32x4 v = *(const f32x4*)(sC + row * 64 + col);
+                if (gm < a.M) {
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e)
+                        if (gn + e < a.N) epilogue_store1<EPI>(a, gm, gn + e, v[e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN: dW[n,k] += alpha * sum_m A[m,n] * B[m,k]
 // ------------------------------------------------------------------------------------------------
 struct GemmTnArgs {
@@ -318,6 +541,156 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN "ring" kernel: dW tile 256 (n) x 256 (k), 8 waves (2 x 4, wave tile 128 x 64), 32 reduction rows per step,
+// 4-stage LDS ring with counted vmcnt like the NT ring kernel.  A stage holds [32 m][256 n] of A and [32 m][256 k]
+// of B as 512-byte rows; 16-byte chunks are XOR-swizzled by (row&3)<<2 so the transposing ds_read_b64_tr_b16 reads
+// (4 consecutive m-rows x 64 B per half-wave) are bank-conflict free.  Split over M fills the chip (one workgroup
+// per CU), so the main loop is long and the fp32-atomic epilogue is amortised.
+// ------------------------------------------------------------------------------------------------
+OCN_DEV bf16x8 frag_tn512(const char* sT, int cb, int s, int lane) {
+    const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+    const int chunk = ((cb + g * 16) >> 3) + ((i & 3) >> 1);
+    const int p = chunk ^ ((i >> 2) << 2);
+    const int row = s * 16 + h * 8 + (i >> 2);
+    const char* base = sT + row * 512 + p * 16 + (i & 1) * 8;
+    const s16x4 lo = lds_read_tr16((const OCN_LDS void*)base);
+    const s16x4 hi = lds_read_tr16((const OCN_LDS void*)(base + 4 * 512));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTnArgs a) {
+    constexpr int HALF = 16384, STAGE = 32768;  // A part + B part
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 * STAGE = 128 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = xcd_remap(blockIdx.x, a.nwg);
+    const int ntile = a.tiles_n * a.tiles_k;
+    const int split = wid / ntile, tile = wid % ntile;
+    const int n0 = (tile / a.tiles_k) * 256, k0 = (tile % a.tiles_k) * 256;
+    const int m_begin = split * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int wn = wave >> 2, wk = wave & 3;
+    const bool do_bias = (a.dbias != nullptr) && (k0 == 0);  // wave wk adds the column sums of A block i == wk
+    const int nk = (m_end - m_begin + 31) / 32;
+
+    // DMA: wave w moves rows {2w, 2w+1} and {16+2w, 17+2w} of each operand's [32][256] stage image
+    int rrow[2], ccol[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        rrow[j] = (wave + j * 8) * 2 + (lane >> 5);
+        ccol[j] = ((lane & 31) ^ ((rrow[j] & 3) << 2)) * 8;
+    }
+    const bf16* pa[2];
+    const bf16* pb[2];
+    bool va[2], vb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        va[j] = (n0 + ccol[j]) < a.N;
+        vb[j] = (k0 + ccol[j]) < a.K;
+        pa[j] = a.A + (size_t)(m_begin + rrow[j]) * a.lda + n0 + ccol[j];
+        pb[j] = a.B + (size_t)(m_begin + rrow[j]) * a.ldb + k0 + ccol[j];
+    }
+    int mrow = m_begin;  // first row of the next stage to issue
+#define OCN_TN_DMA(SLOT)                                                                                         \
+    {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+            const bool inr = (mrow + rrow[j]) < m_end;                                                           \
+            glds16((inr && va[j]) ? (const void*)pa[j] : (const void*)g_zero16,                                  \
+                   (OCN_LDS void*)(smem + (SLOT) * STAGE + (wave + j * 8) * 1024));                              \
+            glds16((inr && vb[j]) ? (const void*)pb[j] : (const void*)g_zero16,                                  \
+                   (OCN_LDS void*)(smem + (SLOT) * STAGE + HALF + (wave + j * 8) * 1024));                       \
+            pa[j] += (size_t)32 * a.lda;                                                                         \
+            pb[j] += (size_t)32 * a.ldb;                                                                         \
+        }                                                                                                        \
+        mrow += 32;                                                                                              \
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        if (s < nk) OCN_TN_DMA(s)
+
+    f32x16 acc[4][2], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    bf16x8 a0[4], b0[2], a1[4], b1[2];
+#define OCN_TN_FRAGS(AF, BF, STG, S)                                                                             \
+    {                                                                                                            \
+        const char* sA_ = smem + ((STG)&3) * STAGE;                                                              \
+        const char* sB_ = sA_ + HALF;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = frag_tn512(sA_, wn * 128 + i * 32, S, lane);        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) BF[j] = frag_tn512(sB_, wk * 64 + j * 32, S, lane);         \
+    }
+#define OCN_TN_MFMA(AF, BF)                                                                                      \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+            acc[i][j] = mfma32(AF[i], BF[j], acc[i][j]);                                                         \
+        if (do_bias) {                                                                                           \
+            if (wk == 0) accb = mfma32(AF[0], ones, accb);                                                       \
+            else if (wk == 1) accb = mfma32(AF[1], ones, accb);                                                  \
+            else if (wk == 2) accb = mfma32(AF[2], ones, accb);                                                  \
+            else accb = mfma32(AF[3], ones, accb);                                                               \
+        }                                                                                                        \
+    }
+#define OCN_TN_STEP(DMA, WAIT4)                                                                                  \
+    {                                                                                                            \
+        if (WAIT4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                              \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_s_barrier();                                                                            \
+        OCN_TN_FRAGS(a1, b1, kt, 1);                                                                             \
+        if (DMA) OCN_TN_DMA((kt + 3) & 3)                                                                        \
+        OCN_TN_MFMA(a0, b0);                                                                                     \
+        const int nstg = kt + 1 < nk ? kt + 1 : kt;                                                              \
+        OCN_TN_FRAGS(a0, b0, nstg, 0);                                                                           \
+        OCN_TN_MFMA(a1, b1);                                                                                     \
+    }
+    if (nk > 0) {
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        OCN_TN_FRAGS(a0, b0, 0, 0);
+        int kt = 0;
+        for (; kt + 3 < nk; ++kt) OCN_TN_STEP(true, true)
+        for (; kt + 2 < nk; ++kt) OCN_TN_STEP(false, true)
+        for (; kt < nk; ++kt) OCN_TN_STEP(false, false)
+    }
+#undef OCN_TN_STEP
+#undef OCN_TN_MFMA
+#undef OCN_TN_FRAGS
+#undef OCN_TN_DMA
+    const int lr = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gk = k0 + wk * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gn = n0 + wn * 128 + i * 32 + mfma32_row(r, lane);
+                if (gn < a.N && gk < a.K) unsafeAtomicAdd(a.dW + (size_t)gn * a.ldw + gk, a.alpha * acc[i][j][r]);
+            }
+        }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gn = n0 + wn * 128 + wk * 32 + mfma32_row(r, lane);
+            if (gn < a.N) unsafeAtomicAdd(a.dbias + gn, a.alpha * accb[r]);
+        }
+    }
+}
+
 template <int EPI, int BM_, int BN_, int WR, int WC>
 int launch_nt_geo(GemmNtArgs a, hipStream_t st) {
     constexpr int LDS = 2 * (BM_ + BN_) * 128;
@@ -336,14 +709,31 @@ int launch_nt_geo(GemmNtArgs a, hipStream_t st) {
     return OCN_OK;
 }
 
-int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128
+int g_tn_variant = 0;  // 0 = auto, 1 = 128x128 two-stage, 2 = 256x256 ring
+int g_nt_ablate = 0;
+int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128, 4 = 256x256 4-stage ring (K % 32)
 
 template <int EPI>
 int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     int v = g_nt_variant;
-    if (v == 0) v = (a.M >= 2048 && a.N >= 256) ? 2 : 1;
+    if (v == 0) v = (a.M >= 1024 && a.N >= 192) ? 4 : 1;
+    if (a.K % 64) v = 4;  // the two-stage kernels step K by 64; the ring kernel by 32
     if (v == 2) return launch_nt_geo<EPI, 256, 256, 2, 4>(a, st);
     if (v == 3) return launch_nt_geo<EPI, 256, 128, 4, 2>(a, st);
+    if (v == 4) {
+        GemmNtArgs b = a;
+        b.ablate = g_nt_ablate;
+        b.tiles_n = ocn_cdiv(b.N, 256);
+        b.ntiles = ocn_cdiv(b.M, 256) * b.tiles_n;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_ring_kernel<EPI>, dim3(b.ntiles), dim3(512), 131072, st, b);
+        OCN_CHECK_LAUNCH("ocn_gemm_nt");
+        return OCN_OK;
+    }
     return launch_nt_geo<EPI, 128, 128, 2, 2>(a, st);
 }
 
@@ -353,7 +743,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
                            int K, const float* bias, const float* resid, void* aux, float alpha, ocn_stream_t stream) {
     OCN_CHECK_ARG(A && B && out, "ocn_gemm_nt: null operand");
     OCN_CHECK_ARG(M > 0 && N > 0 && K > 0, "ocn_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
-    OCN_CHECK_ARG(K % 64 == 0, "ocn_gemm_nt: K=%d must be a multiple of 64", K);
+    OCN_CHECK_ARG(K % 32 == 0, "ocn_gemm_nt: K=%d must be a multiple of 32", K);
     OCN_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "ocn_gemm_nt: bad leading dims");
     OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)out & 15) == 0,
                   "ocn_gemm_nt: operands must be 16-byte aligned");
@@ -362,7 +752,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (bf16*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    a.tiles_n = 0; a.ntiles = 0;
+    a.tiles_n = 0; a.ntiles = 0; a.ablate = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OCN_EPI_BF16: return launch_nt<OCN_EPI_BF16>(a, st);
@@ -376,6 +766,9 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
 }
 
 extern "C" int ocn_set_gemm_variant(int nt_variant) {
+    g_nt_ablate = nt_variant >> 8;   // developer ablation mask in the high bits
+    g_tn_variant = (nt_variant >> 4) & 15;  // bits 4..7: TN kernel choice
+    nt_variant &= 15;
     g_nt_variant = nt_variant;
     return OCN_OK;
 }
@@ -389,17 +782,28 @@ extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb,
     GemmTnArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.dW = dW; a.dbias = dbias;
     a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    a.tiles_n = ocn_cdiv(N, 128);
-    a.tiles_k = ocn_cdiv(K, 128);
+    const bool ring = (g_tn_variant == 2) || (g_tn_variant == 0 && (long)M * N * K >= (1L << 31) && N >= 256 && K >= 256);
+    const int T = ring ? 256 : 128, RS = ring ? 32 : 64;
+    a.tiles_n = ocn_cdiv(N, T);
+    a.tiles_k = ocn_cdiv(K, T);
     const int ntile = a.tiles_n * a.tiles_k;
-    const int msteps = ocn_cdiv(M, 64);
-    int splits = ocn_cdiv(1536, ntile);          // ~3 waves of workgroups over 256 CUs x 2
+    const int msteps = ocn_cdiv(M, RS);
+    int splits = ring ? (256 / ntile > 0 ? 256 / ntile : 1) : ocn_cdiv(1536, ntile);  // ring: one workgroup per CU
     if (splits > msteps) splits = msteps;
     if (splits < 1) splits = 1;
-    a.chunk = ocn_cdiv(msteps, splits) * 64;
+    a.chunk = ocn_cdiv(msteps, splits) * RS;
     splits = ocn_cdiv(M, a.chunk);
     a.nwg = splits * ntile;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    if (ring) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(a.nwg), dim3(512), 131072, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    }
     OCN_CHECK_LAUNCH("ocn_gemm_tn_accum");
     return OCN_OK;
 }

@@ -117,6 +117,56 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     check(tag + " dgelu", out, ref * x.grad, bf16_out=True, abs_tol=1e-3)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 640, 320), (2500, 768, 1024), (513, 1027, 96)])
+def test_gemm_nt_every_kernel_variant(dev, variant, M, N, K):
+    """each NT tile geometry / pipeline (include/openclip_hip.h: ocn_set_gemm_variant) on ragged shapes, incl. a
+    non-multiple-of-4 N (scalar epilogue path) and K = 96 (3 ring stages) / K = 64 (2 stages)"""
+    from open_clip_amd import _lib, ops
+    if variant != 4 and K % 64:
+        pytest.skip("two-stage kernels need K % 64 == 0")
+    g = torch.Generator().manual_seed(variant * 100 + M)
+    a = bf(torch.randn(M, K, generator=g)).to(dev)
+    b = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    bias, resid = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    fpre = bf(torch.randn(M, N, generator=g)).to(dev)
+    ref = a.float() @ b.float().t()
+    try:
+        _lib.call("ocn_set_gemm_variant", variant)
+        tag = f"gemm_nt.v{variant}[{M}x{N}x{K}]"
+        out = ops.gemm_nt(ops.EPI_F32, a, b, torch.empty(M, N, device=dev), bias=bias, alpha=2.0)
+        check(tag + " f32", out, 2.0 * ref + bias, rel=2e-5)
+        out = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, b, torch.empty(M, N, device=dev), bias=bias, resid=resid)
+        check(tag + " resid", out, ref + bias + resid, rel=2e-5)
+        out = ops.gemm_nt(ops.EPI_DGELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), aux=fpre)
+        x = fpre.float().requires_grad_(True)
+        torch.nn.functional.gelu(x).backward(torch.ones_like(x))
+        check(tag + " dgelu", out, ref * x.grad, bf16_out=True, abs_tol=1e-3)
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        out = ops.gemm_nt(ops.EPI_BIAS_GELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=bias, aux=aux)
+        check(tag + " gelu.out", out, torch.nn.functional.gelu(ref + bias), bf16_out=True, abs_tol=1e-3)
+        check(tag + " gelu.pre", aux, ref + bias, bf16_out=True)
+    finally:
+        _lib.call("ocn_set_gemm_variant", 0)
+
+
+@pytest.mark.parametrize("tv", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(3000, 640, 328), (100, 264, 520), (40000, 512, 256)])
+def test_gemm_tn_every_kernel_variant(dev, tv, M, N, K):
+    from open_clip_amd import _lib, ops
+    g = torch.Generator().manual_seed(tv * 10 + M)
+    a = bf(torch.randn(M, N, generator=g)).to(dev)
+    b = bf(torch.randn(M, K, generator=g)).to(dev)
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    try:
+        _lib.call("ocn_set_gemm_variant", tv << 4)
+        ops.gemm_tn_accum(a, b, dw, db)
+    finally:
+        _lib.call("ocn_set_gemm_variant", 0)
+    check(f"gemm_tn.v{tv}[{M}x{N}x{K}] dW", dw, a.float().t() @ b.float(), rel=1e-4)
+    check(f"gemm_tn.v{tv}[{M}x{N}x{K}] dbias", db, a.float().sum(0), rel=1e-4)
+
+
 def test_gemm_nt_strided_views(dev):
     from open_clip_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -333,6 +383,6 @@ def test_ops_fail_loudly_on_cpu_tensors(dev):
     from open_clip_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.cast_bf16(torch.randn(8))
-    with pytest.raises(RuntimeError, match="K=.*multiple of 64"):
-        a = torch.zeros(8, 32, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError, match="K=.*multiple of 32"):
+        a = torch.zeros(8, 48, dtype=torch.bfloat16, device=dev)
         ops.gemm_nt(ops.EPI_F32, a, a, torch.zeros(8, 8, device=dev))

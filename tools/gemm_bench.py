@@ -14,6 +14,7 @@ SHAPES_NT = [  # (name, M, N, K)
     ("img qkv", Mi, 2304, 768), ("img out", Mi, 768, 768), ("img fc", Mi, 3072, 768), ("img proj", Mi, 768, 3072),
     ("txt qkv", Mt, 1536, 512), ("txt out", Mt, 512, 512), ("txt fc", Mt, 2048, 512), ("txt proj", Mt, 512, 2048),
 ]
+# variant ids may carry a developer ablation mask in bits 8+: 4 + 256*mask
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3".split(","))]
 epis = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3".split(","))]
 
@@ -33,6 +34,8 @@ def timeit(fn, iters=6):
 def check(variant):
     _lib.call("ocn_set_gemm_variant", variant)
     g = torch.Generator().manual_seed(0)
+    if variant >> 8:
+        return float("nan")
     M, N, K = 1000, 640, 320
     a = torch.randn(M, K, generator=g).bfloat16().to(dev)
     b = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(dev)
@@ -68,12 +71,27 @@ for name, M, N, K in SHAPES_NT:
 print("sum ms per variant:", {v: round(t, 2) for v, t in tot.items()})
 _lib.call("ocn_set_gemm_variant", 0)
 
-print("TN (wgrad):")
+print("TN (wgrad): variant 1 = 128x128 two-stage, 2 = 256x256 ring")
+for tv in (1, 2):
+    _lib.call("ocn_set_gemm_variant", tv << 4)
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 3000, 640, 328
+    a = torch.randn(M, N, generator=g).bfloat16().to(dev)
+    b = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.gemm_tn_accum(a, b, dw, db)
+    ref = a.float().t() @ b.float()
+    print(f"  TN variant {tv}: dW rel_l2 = {float((dw - ref).norm() / ref.norm()):.2e}  dbias rel_l2 = {float((db - a.float().sum(0)).norm() / a.float().sum(0).norm()):.2e}")
 for name, M, N, K in SHAPES_NT:
     a = torch.randn(M, N, device=dev).bfloat16()
     b = torch.randn(M, K, device=dev).bfloat16()
     dw = torch.zeros(N, K, device=dev)
     db = torch.zeros(N, device=dev)
-    ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
-    print(f"{name:10s} dW[{N},{K}] over M={M}: {2.0 * M * N * K / ms / 1e9:7.0f} TFLOP/s  {ms:.3f} ms")
+    row = []
+    for tv in (1, 2):
+        _lib.call("ocn_set_gemm_variant", tv << 4)
+        ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
+        row.append(f"v{tv}: {2.0 * M * N * K / ms / 1e9:6.0f} TF/s {ms:.3f} ms")
+    print(f"{name:10s} dW[{N},{K}] over M={M}:  " + "   ".join(row))
     del a, b
+_lib.call("ocn_set_gemm_variant", 0)
