@@ -316,15 +316,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int a_row = (wm * 128 + lr) * 64, b_row = (wn * 64 + lr) * 64;
+    const unsigned lds_base = (unsigned)(size_t)(OCN_LDS char*)smem;
     const int sw = swz64(lr);
     const int cpos0 = ((0 + lh) ^ sw) << 4, cpos1 = ((2 + lh) ^ sw) << 4;  // k-substeps 0 / 1 of a stage
     bf16x8 a0[4], b0[2], a1[4], b1[2];
+    // Fragment reads are inline asm so that hipcc does not count them: its own bookkeeping waits lgkmcnt(0) for
+    // loop-carried reads, which exposes the LDS latency of the reads issued just before.  Waits are placed by hand
+    // (LDS returns in order): every read group has 8 MFMAs of cover before the counted wait that retires it, and the
+    // loop-carried fragments are complete at the back-edge (so compiler copies of them are safe).
 #define OCN_LOAD_FRAGS(AF, BF, STG, CPOS)                                                        \
     {                                                                                            \
-        const char* sA_ = smem + ((STG)&3) * STAGE;                                              \
-        const char* sB_ = sA_ + A_BYTES;                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = *(const bf16x8*)(sA_ + a_row + i * 32 * 64 + (CPOS)); \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) BF[j] = *(const bf16x8*)(sB_ + b_row + j * 32 * 64 + (CPOS)); \
+        const unsigned sA_ = lds_base + (unsigned)(((STG)&3) * STAGE + a_row + (CPOS));           \
+        const unsigned sB_ = lds_base + (unsigned)(((STG)&3) * STAGE + A_BYTES + b_row + (CPOS)); \
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\t"              \
+                     "ds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"       \
+                     : "=&v"(AF[0]), "=&v"(AF[1]), "=&v"(AF[2]), "=&v"(AF[3]) : "v"(sA_));            \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048"                   \
+                     : "=&v"(BF[0]), "=&v"(BF[1]) : "v"(sB_));                                      \
     }
 #define OCN_MFMA_BLOCK(AF, BF)                                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(AF[i], BF[j], acc[i][j]);
@@ -335,6 +343,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     OCN_LOAD_FRAGS(a0, b0, 0, cpos0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // One K-step.  Fragments of (kt, k-substep 0) are already in registers.  Make stage kt+1 visible (its first
     // fragments are fetched at the end of the step); stage kt+2 may stay in flight (4 DMA ops per stage per wave).
     // The 4 DMA issues of stage kt+3 are spread between the first MFMAs so that they sit in the shadow of queued
@@ -343,9 +353,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs a) {
     {                                                                                              \
         if (WAIT4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
-        if (!(a.ablate & 2)) __builtin_amdgcn_s_barrier();                                         \
+        __builtin_amdgcn_s_barrier();                                                              \
         const int slot = (kt + 3) & 3;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
         OCN_LOAD_FRAGS(a1, b1, kt, cpos1);                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
         acc[0][0] = mfma32(a0[0], b0[0], acc[0][0]);                                               \
         acc[0][1] = mfma32(a0[0], b0[1], acc[0][1]);                                               \
         if (DMA) { OCN_DMA_A(0, slot) }                                                            \
@@ -359,13 +371,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs a) {
         acc[3][1] = mfma32(a0[3], b0[1], acc[3][1]);                                               \
         if (DMA) { OCN_DMA_B(1, slot) }                                                            \
         const int nstg = kt + 1 < nk ? kt + 1 : kt;                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
         OCN_LOAD_FRAGS(a0, b0, nstg, cpos0);                                                       \
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");  /* a1, b1 landed */                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
         OCN_MFMA_BLOCK(a1, b1);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* a0, b0 of the next step landed */   \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
     }
     int kt = 0;
-    if (!(a.ablate & 1)) {
-        for (; kt + 3 < nk; ++kt) OCN_RING_STEP(true, true)
-    }
+    for (; kt + 3 < nk; ++kt) OCN_RING_STEP(true, true)
     for (; kt + 2 < nk; ++kt) OCN_RING_STEP(false, true)
     for (; kt < nk; ++kt) OCN_RING_STEP(false, false)
 #undef OCN_RING_STEP
