@@ -11,7 +11,7 @@
 //   NT  : rows of 64 bf16 (128 B), ds_read_b128 fragments, chunk ^= f(row)          (f: see swz_nt)
 //   TN  : rows of 128 bf16 (256 B), ds_read_b64_tr_b16 transposing reads, chunk ^= (row&3)<<2
 // Tiles are walked in an XCD-aware order (ocn_common.h xcd_remap).
-#include "ocn_common.h"
+#include "gemm_args.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -23,24 +23,6 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // double buffered: 64 KiB -> 2 workgroups / CU
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];  // zero source for out-of-range DMA lanes
-
-// chunk swizzle for 128-byte rows: bijection on 3 bits built from row bits 1..3, chosen so that
-// (a) the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots and
-// (b) 4 consecutive rows land in different 64-byte quarters (needed by tr16 reads of the same image).
-OCN_DEV int swz_nt(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
-
-struct GemmNtArgs {
-    const bf16* A;
-    const bf16* B;
-    void* out;
-    const float* bias;
-    const float* resid;
-    bf16* aux;
-    int lda, ldb, ldc, M, N, K;
-    float alpha;
-    int tiles_n, ntiles;
-    int ablate;  // developer ablation mask (tools/gemm_bench.py): 1 = no in-loop DMA, 2 = no in-loop barrier
-};
 
 // rows [row0, row0+ROWS) x k [k0, k0+64) of a row-major bf16 matrix -> LDS tile (rows clamped), NW waves
 template <int ROWS, int NW>
@@ -727,12 +709,19 @@ int launch_nt_geo(GemmNtArgs a, hipStream_t st) {
 
 int g_tn_variant = 0;  // 0 = auto, 1 = 128x128 two-stage, 2 = 256x256 ring
 int g_nt_ablate = 0;
-int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128, 4 = 256x256 4-stage ring (K % 32)
+int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128, 4 = 256x256 4-stage ring (K % 32), 5 = persistent 256x256 (K % 128)
 
 template <int EPI>
 int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     int v = g_nt_variant;
-    if (v == 0) v = (a.M >= 1024 && a.N >= 192) ? 4 : 1;
+    if (v == 0) v = (a.M >= 1024 && a.N >= 192) ? 5 : 1;
+    if (v == 5) {  // persistent 256x256 kernel (gemm_nt5.hip); falls through when the shape does not fit it
+        GemmNtArgs a5 = a;
+        a5.ablate = g_nt_ablate;
+        const int rc = ocn_launch_nt5(EPI, a5, st);
+        if (rc <= 0) return rc;
+        v = (a.M >= 1024 && a.N >= 192) ? 4 : 1;
+    }
     if (a.K % 64) v = 4;  // the two-stage kernels step K by 64; the ring kernel by 32
     if (v == 2) return launch_nt_geo<EPI, 256, 256, 2, 4>(a, st);
     if (v == 3) return launch_nt_geo<EPI, 256, 128, 4, 2>(a, st);

@@ -1,0 +1,24 @@
+// Argument block shared by the NT GEMM kernels (gemm.hip, gemm_nt5.hip).
+#pragma once
+#include "ocn_common.h"
+
+struct GemmNtArgs {
+    const bf16* A;
+    const bf16* B;
+    void* out;
+    const float* bias;
+    const float* resid;
+    bf16* aux;
+    int lda, ldb, ldc, M, N, K;
+    float alpha;
+    int tiles_n, ntiles;
+    int ablate;  // developer ablation mask (tools/gemm_bench.py)
+};
+
+// chunk swizzle for 128-byte LDS rows: bijection on 3 bits built from row bits 1..3, chosen so that
+// (a) the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots and
+// (b) 4 consecutive rows land in different 64-byte quarters (needed by tr16 reads of the same image).
+OCN_DEV int swz_nt(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// persistent 256x256 NT kernel (gemm_nt5.hip); returns 1 if the shape is not supported by it (caller falls back)
+int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st);

@@ -1,0 +1,477 @@
+// Persistent NT GEMM for the big tower GEMMs on gfx950:  C[M,N] = A[M,K] . B[N,K]^T  (+ fused epilogue).
+//
+// One workgroup per CU (8 waves, 160 KiB LDS) walks its share of the 256x256 output tiles; the operand stream never
+// drains between tiles.  What the measurements on the MI355X said (tools/probes/dma_probe.hip):
+//   * the L2 -> LDS feed is the binding resource of a 256x256 bf16 tile (52-68 GB/s per CU achievable, 62-75 needed
+//     at the MFMA peak); LDS-DMA instructions that fetch FULL 128-byte lines (8 rows x 128 B) move ~25 % more than
+//     ones that fetch half lines (16 rows x 64 B)  ->  K is consumed in 64-wide tiles (128-byte LDS rows);
+//   * a non-persistent workgroup pays ~8 us per tile for launch + first-load latency + a serialized epilogue
+//     ->  the DMA ring runs 1.5 K-tiles ahead ACROSS tile boundaries and the epilogue's stores are fire-and-forget.
+//
+// K-tile = 64 k.  Operand units of 16 KiB (128 rows x 128 B): A0/A1 = the rows of the two 64-row halves of every wave's
+// 128-row strip, B0/B1 = the two 32-column halves of every wave's 64-column strip.  LDS ring = 2 K-tiles x 4 units.
+// A K-tile is two phases of 16 MFMAs per wave: even = A0 x (B0,B1), odd = A1 x (B0,B1) with the B fragments kept in
+// registers.  One raw s_barrier + one counted vmcnt per phase:
+//   even phase of K-tile g: wait vmcnt(6) -> barrier -> issue A1(g+1)              [2 DMA per wave]
+//   odd  phase of K-tile g: wait vmcnt(2) -> barrier -> issue A0,B0,B1(g+2)        [6 DMA per wave]
+// so every unit is issued >= 2 phases before the barrier that publishes it and into a slot whose last reader retired
+// (lgkmcnt(0)) before the barrier preceding the issue.  Fragment reads are inline asm (hipcc would wait lgkmcnt(0)
+// right after issuing loop-carried reads); each read group has 4 MFMAs of cover.
+// The MFMAs compute C^T tiles (B fragment first), so a lane owns ONE row of C and 4 consecutive columns per
+// register quad: the epilogue converts in registers, transposes through a private 4 KiB LDS staging buffer with
+// ds_write_b64/b128, and stores whole 128-byte rows.
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int UNIT = 16384;
+constexpr int RING_BYTES = 8 * UNIT;
+constexpr int STG_BYTES = 4096;
+constexpr int LDS_BYTES = RING_BYTES + 8 * STG_BYTES;  // 163840 = all of a CU's LDS
+
+#define A_SLOT(HA, P) (((HA)*2 + (P)) * 16384)
+#define B_SLOT(HB, P) (65536 + ((HB)*2 + (P)) * 16384)  // LDS byte offset (DMA destination)
+#define B_RD(HB, P) (((HB)*2 + (P)) * 16384)            // ds_read immediate (the 64 KiB base is in the address VGPR)
+
+#define DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
+#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// Epilogue staging goes through inline-asm LDS ops: for compiler-visible LDS reads hipcc inserts s_waitcnt vmcnt(0)
+// (it cannot prove they do not alias an in-flight LDS-DMA), which would serialize every global store of the epilogue
+// behind a full memory round trip (measured: 10 us per tile instead of ~1).
+OCN_DEV void lds_w64(unsigned addr, bf16x4 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+OCN_DEV void lds_w128(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <typename T>
+OCN_DEV void lds_r128x4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, T& d0, T& d1, T& d2, T& d3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
+}
+
+// Global accesses of the epilogue are BUFFER instructions on descriptors that start at the tile's first row: rows
+// beyond M and (by forcing the offset out of range) columns beyond N are dropped / read as zero by the bounds check, so
+// the whole epilogue is one basic block and hipcc can keep counted vmcnt waits (with exec-masked branches around the
+// stores it falls back to vmcnt(0) before every store).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+constexpr unsigned OOB = 0x80000000u;
+
+OCN_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long row0, int rows_total, int ld, int esz) {
+    long bytes = (long)(rows_total - row0) * ld * esz;
+    if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+    if (bytes < 0) bytes = 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + row0 * ld * esz), 0, (int)bytes, 0x00020000);
+}
+
+template <int EPI>
+OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg) {
+    // Lane constants are laundered through an empty asm once per tile: otherwise hipcc hoists ~40 VGPRs of epilogue
+    // addresses (per-row store offsets, swizzled staging addresses) out of the tile loop and keeps them live across the
+    // main loop, which is already at the 256-register budget.
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int lr = lane_o & 31, lh = lane_o >> 5;
+    const int gn_w = n0 + wn * 64;
+    const int rd_row = lane_o >> 3, rd_chunk = lane_o & 7;
+    const unsigned rd_addr = stg + rd_row * 128 + ((rd_chunk ^ rd_row) << 4);  // + it * 1024 for rows it*8 + rd_row
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_BIAS_GELU);
+    constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
+    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m0, a.M, a.ldc, OUT_F32 ? 4 : 2);
+    const __amdgpu_buffer_rsrc_t r_aux = tile_rsrc(a.aux, m0, a.M, a.ldc, 2);
+    const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, a.M, a.ldc, 4);
+    const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+    // Bias is fetched ONCE, before any store of this tile is issued (a later load would have to wait behind the stores):
+    // bf16-staged epilogues add it in the accumulator layout (before rounding), fp32-staged ones after the transpose.
+    f32x4 bv[2][4], bq[2];
+    if (BF16_STAGED) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bv[hb][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + 8 * g + 4 * lh) * 4, 0, 0));
+    } else {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+            bq[hb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + rd_chunk * 4) * 4, 0, 0));
+    }
+    // Every DMA issued so far must have landed: the first phases of the next tile then need no vmcnt wait and the
+    // stores below drain under them.  The wait is the BUILTIN (vmcnt(0), other counters untouched) so that hipcc's
+    // own scoreboard sees it: with LDS-DMA events it believes pending it turns every later load/store wait of the
+    // epilogue into vmcnt(0), i.e. one full memory round trip per store.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    const int row_w = wm * 128;  // this wave's first row inside the tile
+    if (BF16_STAGED) {
+        constexpr int ROUNDS = (EPI == OCN_EPI_BIAS_GELU) ? 2 : 1;
+        const int gn = gn_w + rd_chunk * 8;
+        const unsigned col_off = gn < a.N ? (unsigned)gn * 2u : OOB;
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
+                            if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else v = v + bv[hb][g];
+                            if (EPI == OCN_EPI_BIAS_GELU && rnd == 1) v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                            const bf16x4 pk = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                            lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk);
+                        }
+                    }
+                    const bool to_aux = (EPI == OCN_EPI_BIAS_GELU && rnd == 0);
+                    bf16x8 d[4];
+                    lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
+                        const unsigned off = (unsigned)(row * a.ldc) * 2u + col_off;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, 0);
+                    }
+                }
+    } else {
+        // 32x32 fp32 blocks (128-byte rows).  The epilogue operand of block k+1 (residual rows / saved pre-activation)
+        // is fetched BEFORE block k's stores are issued, so waiting for it never drains the stores.
+        constexpr bool HAS_EX = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_DGELU);
+        unsigned colmask[2];  // OR-ed into byte offsets: pushes out-of-range columns past the descriptor's bound (no select, no branch)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) colmask[hb] = (gn_w + hb * 32 + rd_chunk * 4) < a.N ? 0u : OOB;
+        auto byte_off = [&](int blk, int it, unsigned esz) -> unsigned {  // this lane's 4 columns, row it*8+rd_row of block blk
+            const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
+            const int gn = gn_w + hb * 32 + rd_chunk * 4;
+            const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
+            return ((unsigned)(row * a.ldc + gn) * esz) | colmask[hb];
+        };
+        auto load_ex = [&](int blk, f32x4 (&ex)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (EPI == OCN_EPI_BIAS_RESID_F32) {
+                    ex[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, 0));
+                } else if (EPI == OCN_EPI_DGELU) {
+                    const bf16x4 p4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_aux, byte_off(blk, it, 2u), 0, 0));
+                    ex[it] = (f32x4){bf2f(p4[0]), bf2f(p4[1]), bf2f(p4[2]), bf2f(p4[3])};
+                }
+            }
+        };
+        f32x4 exA[4], exB[4];
+        if (HAS_EX) load_ex(0, exA);
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+            const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
+            f32x4 (&ex)[4] = (blk & 1) ? exB : exA;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
+                lds_w128(stg + lr * 128 + (((g * 2 + lh) ^ (lr & 7)) << 4), v);
+            }
+            f32x4 d[4];
+            lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
+            if (HAS_EX && blk + 1 < 8) load_ex(blk + 1, (blk & 1) ? exA : exB);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
+                if (EPI == OCN_EPI_BIAS_RESID_F32) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, 0);
+                } else if (EPI == OCN_EPI_DGELU) {
+                    const bf16x4 o4 = {f2bf(v[0] * dgelu_f(ex[it][0])), f2bf(v[1] * dgelu_f(ex[it][1])),
+                                       f2bf(v[2] * dgelu_f(ex[it][2])), f2bf(v[3] * dgelu_f(ex[it][3]))};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// DBG = developer build of the same kernel that logs a per-tile timeline into a.aux (tools/gemm_trace.py; plain bf16
+// epilogue only); the production instantiation folds it away.
+template <int EPI, bool DBG>
+__global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nk = a.K >> 6;  // K-tiles per output tile (even)
+    const int G = gridDim.x;
+    const int my_tiles = (a.ntiles - (int)blockIdx.x + G - 1) / G;
+    const unsigned lds_base = (unsigned)(size_t)(OCN_LDS char*)smem;
+
+    // fragment read addresses: unit row (wave strip + lane&31), 16-byte chunk ((ks*2 + lh) ^ swz) = (q<<4) ^ (ks<<5)
+    unsigned va[4], vb[4];
+    {
+        const int q = lh ^ swz_nt(lr);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned o = (unsigned)((q << 4) ^ (ks << 5));
+            va[ks] = lds_base + (unsigned)((wm * 64 + lr) * 128) + o;
+            vb[ks] = lds_base + 65536u + (unsigned)((wn * 32 + lr) * 128) + o;
+        }
+    }
+
+    // ---- DMA cursors: per-lane source pointers of this wave's two instructions per unit ----
+    const bf16* pA0[2];
+    const bf16* pA1[2];
+    const bf16* pB0[2];
+    const bf16* pB1[2];
+    int ab_i = 0, ab_kt = 0, a1_i = 0, a1_kt = 0;  // (tile ordinal, K-tile) each cursor issues next
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        const int tile = xcd_remap((int)blockIdx.x + i * G, a.ntiles);
+        m0 = (tile / a.tiles_n) * 256;
+        n0 = (tile % a.tiles_n) * 256;
+    };
+    auto set_a1 = [&](int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = (wave * 2 + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_nt(u);
+            int m = m0 + (u >> 6) * 128 + 64 + (u & 63);
+            m = m < a.M ? m : a.M - 1;
+            pA1[j] = a.A + (size_t)m * a.lda + c * 8;
+        }
+    };
+    auto set_ab = [&](int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = (wave * 2 + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_nt(u);
+            int m = m0 + (u >> 6) * 128 + (u & 63);
+            m = m < a.M ? m : a.M - 1;
+            pA0[j] = a.A + (size_t)m * a.lda + c * 8;
+            int n = n0 + (u >> 5) * 64 + (u & 31);
+            int n1 = n + 32;
+            n = n < a.N ? n : a.N - 1;
+            n1 = n1 < a.N ? n1 : a.N - 1;
+            pB0[j] = a.B + (size_t)n * a.ldb + c * 8;
+            pB1[j] = a.B + (size_t)n1 * a.ldb + c * 8;
+        }
+    };
+    const int wave_dst = wave * 2048;  // this wave's 2 x 1 KiB pieces inside a unit
+#define DMA(PTR, J, SLOT)                                                        \
+    {                                                                            \
+        glds16(PTR[J], (OCN_LDS void*)(smem + (SLOT) + wave_dst + (J)*1024));    \
+        PTR[J] += 64;                                                            \
+    }
+    auto adv_a1 = [&]() {
+        if (++a1_kt == nk) {
+            a1_kt = 0;
+            if (a1_i + 1 < my_tiles) {
+                ++a1_i;
+                set_a1(a1_i);
+            } else {  // nothing left: keep re-fetching the last tile (valid addresses, results unused)
+                pA1[0] -= (size_t)nk * 64;
+                pA1[1] -= (size_t)nk * 64;
+            }
+        }
+    };
+    auto adv_ab = [&]() {
+        if (++ab_kt == nk) {
+            ab_kt = 0;
+            if (ab_i + 1 < my_tiles) {
+                ++ab_i;
+                set_ab(ab_i);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pA0[j] -= (size_t)nk * 64;
+                    pB0[j] -= (size_t)nk * 64;
+                    pB1[j] -= (size_t)nk * 64;
+                }
+            }
+        }
+    };
+
+    if (a.ablate & 1024) {  // EXPERIMENT: skew the workgroups over one tile period so that epilogue store bursts do not coincide
+        const int slot = (((int)blockIdx.x >> 3) * 13) & 31;                 // spread the CUs of an XCD over 32 slots
+        const long long wait = (long long)slot * (nk * 200 + 300) / 32;      // wall-clock ticks (100 MHz); tile ~ nk*2us + 3us
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+    // ---- prologue: K-tiles 0 and 1 (minus A1(1)) ----
+    set_ab(0);
+    set_a1(0);
+    DMA(pA0, 0, A_SLOT(0, 0)) DMA(pA0, 1, A_SLOT(0, 0)) DMA(pB0, 0, B_SLOT(0, 0)) DMA(pB0, 1, B_SLOT(0, 0))
+    DMA(pB1, 0, B_SLOT(1, 0)) DMA(pB1, 1, B_SLOT(1, 0))
+    adv_ab();
+    DMA(pA1, 0, A_SLOT(1, 0)) DMA(pA1, 1, A_SLOT(1, 0))
+    adv_a1();
+    DMA(pA0, 0, A_SLOT(0, 1)) DMA(pA0, 1, A_SLOT(0, 1)) DMA(pB0, 0, B_SLOT(0, 1)) DMA(pB0, 1, B_SLOT(0, 1))
+    DMA(pB1, 0, B_SLOT(1, 1)) DMA(pB1, 1, B_SLOT(1, 1))
+    adv_ab();
+
+    f32x16 acc[2][2][2];  // [A half][32-row sub-block][B half], each a 32x32 C^T tile
+    bf16x8 fa[2][2];      // A fragments: [buffer][sub-block]
+    bf16x8 fb[2][4];      // B fragments of the whole K-tile: [B half][k-substep]
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#define MM(HA, FA, KS)                                                        \
+    acc[HA][0][0] = mfma32(fb[0][KS], FA[0], acc[HA][0][0]);                  \
+    acc[HA][0][1] = mfma32(fb[1][KS], FA[0], acc[HA][0][1]);                  \
+    acc[HA][1][0] = mfma32(fb[0][KS], FA[1], acc[HA][1][0]);                  \
+    acc[HA][1][1] = mfma32(fb[1][KS], FA[1], acc[HA][1][1]);
+#define RD_A(FA, KS, HA, P) DSR(FA[0], va[KS], A_SLOT(HA, P)); DSR(FA[1], va[KS], A_SLOT(HA, P) + 4096);
+#define RD_B(KS, P) DSR(fb[0][KS], vb[KS], B_RD(0, P)); DSR(fb[1][KS], vb[KS], B_RD(1, P));
+
+    // one K-tile held in ring parity P; SKIP: the epilogue (or prologue) before it already drained every DMA
+#define KTILE(P, SKIP, LAST)                                                                          \
+    {                                                                                             \
+        /* ---- even phase: A0 x (B0, B1) ---- */                                                 \
+        if (!(SKIP)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+        __builtin_amdgcn_s_barrier();                                                             \
+        SB();                                                                                     \
+        RD_A(fa[1], 1, 0, P) RD_B(1, P)                                                           \
+        SB();                                                                                     \
+        acc[0][0][0] = mfma32(fb[0][0], fa[0][0], acc[0][0][0]);                                  \
+        acc[0][0][1] = mfma32(fb[1][0], fa[0][0], acc[0][0][1]);                                  \
+        DMA(pA1, 0, A_SLOT(1, (P) ^ 1))                                                           \
+        acc[0][1][0] = mfma32(fb[0][0], fa[0][1], acc[0][1][0]);                                  \
+        DMA(pA1, 1, A_SLOT(1, (P) ^ 1))                                                           \
+        acc[0][1][1] = mfma32(fb[1][0], fa[0][1], acc[0][1][1]);                                  \
+        SB(); LGKM0(); SB();                                                                      \
+        RD_A(fa[0], 2, 0, P) RD_B(2, P)                                                           \
+        SB();                                                                                     \
+        MM(0, fa[1], 1)                                                                           \
+        SB(); LGKM0(); SB();                                                                      \
+        RD_A(fa[1], 3, 0, P) RD_B(3, P)                                                           \
+        SB();                                                                                     \
+        MM(0, fa[0], 2)                                                                           \
+        adv_a1();                                                                                 \
+        SB(); LGKM0(); SB();                                                                      \
+        RD_A(fa[0], 0, 1, P)                                                                      \
+        SB();                                                                                     \
+        MM(0, fa[1], 3)                                                                           \
+        SB(); LGKM0(); SB();                                                                      \
+        /* ---- odd phase: A1 x (B0, B1), B fragments from registers ---- */                      \
+        if (!(SKIP)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                             \
+        __builtin_amdgcn_s_barrier();                                                             \
+        SB();                                                                                     \
+        RD_A(fa[1], 1, 1, P)                                                                      \
+        SB();                                                                                     \
+        acc[1][0][0] = mfma32(fb[0][0], fa[0][0], acc[1][0][0]);                                  \
+        DMA(pA0, 0, A_SLOT(0, P))                                                                 \
+        acc[1][0][1] = mfma32(fb[1][0], fa[0][0], acc[1][0][1]);                                  \
+        DMA(pA0, 1, A_SLOT(0, P))                                                                 \
+        acc[1][1][0] = mfma32(fb[0][0], fa[0][1], acc[1][1][0]);                                  \
+        DMA(pB0, 0, B_SLOT(0, P))                                                                 \
+        acc[1][1][1] = mfma32(fb[1][0], fa[0][1], acc[1][1][1]);                                  \
+        DMA(pB0, 1, B_SLOT(0, P))                                                                 \
+        SB(); LGKM0(); SB();                                                                      \
+        RD_A(fa[0], 2, 1, P)                                                                      \
+        SB();                                                                                     \
+        acc[1][0][0] = mfma32(fb[0][1], fa[1][0], acc[1][0][0]);                                  \
+        DMA(pB1, 0, B_SLOT(1, P))                                                                 \
+        acc[1][0][1] = mfma32(fb[1][1], fa[1][0], acc[1][0][1]);                                  \
+        DMA(pB1, 1, B_SLOT(1, P))                                                                 \
+        acc[1][1][0] = mfma32(fb[0][1], fa[1][1], acc[1][1][0]);                                  \
+        acc[1][1][1] = mfma32(fb[1][1], fa[1][1], acc[1][1][1]);                                  \
+        SB(); LGKM0(); SB();                                                                      \
+        RD_A(fa[1], 3, 1, P)                                                                      \
+        SB();                                                                                     \
+        MM(1, fa[0], 2)                                                                           \
+        adv_ab();                                                                                 \
+        SB(); LGKM0(); SB();                                                                      \
+        /* first fragments of the next K-tile (ring parity P^1; published by this phase's barrier) */ \
+        if (!(LAST)) { RD_A(fa[0], 0, 0, (P) ^ 1) RD_B(0, (P) ^ 1) }                              \
+        SB();                                                                                     \
+        MM(1, fa[1], 3)                                                                           \
+        SB(); LGKM0(); SB();                                                                      \
+    }
+
+    const unsigned stg = lds_base + RING_BYTES + wave * STG_BYTES;
+    long long* dbg = nullptr;
+    if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = (long long*)a.aux + (blockIdx.x ? 512 : 0);
+#define STAMP(IDX) if (DBG && dbg && i < 8) dbg[i * 8 + (IDX)] = wall_clock64();
+    for (int i = 0; i < my_tiles; ++i) {
+        STAMP(0)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][y][z][r] = 0.f;
+        // first fragments of the tile (its K-tile 0 was published by a barrier before the previous epilogue / prologue)
+        SB();
+        RD_A(fa[0], 0, 0, 0) RD_B(0, 0)
+        LGKM0();
+        SB();
+        for (int kt = 0; kt < nk; kt += 2) {
+            const bool skip = (kt == 0);
+            KTILE(0, skip, false)
+            KTILE(1, false, kt + 2 >= nk)
+        }
+        STAMP(3)
+        int m0, n0;
+        tile_origin(i, m0, n0);
+        epilogue5<EPI>(a, acc, m0, n0, wm, wn, lane, stg);
+        STAMP(4)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released
+#undef KTILE
+#undef MM
+#undef RD_A
+#undef RD_B
+#undef DMA
+}
+
+int g_num_cu = 0;
+
+template <int EPI>
+int launch5(GemmNtArgs a, hipStream_t st) {
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cu = n;
+    }
+    a.tiles_n = ocn_cdiv(a.N, 256);
+    a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
+    const int grid = a.ntiles < g_num_cu ? a.ntiles : g_num_cu;
+    if ((a.ablate & 64) && EPI == OCN_EPI_BF16) {  // developer build (ablations / timeline), plain bf16 epilogue only
+        static bool dbg_attr_set = false;
+        if (!dbg_attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<OCN_EPI_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            dbg_attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt5_kernel<OCN_EPI_BF16, true>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+        OCN_CHECK_LAUNCH("ocn_gemm_nt");
+        return OCN_OK;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+    OCN_CHECK_LAUNCH("ocn_gemm_nt");
+    return OCN_OK;
+}
+
+}  // namespace
+
+int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
+    // needs whole 128-k pairs of K-tiles, 16-byte aligned bf16 rows on the output side and vector-width columns
+    if (a.K % 128 != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 1;
+    if ((long)a.ldc * 4 * 256 >= 0x7fffffffL) return 1;  // 32-bit buffer offsets inside a tile
+    switch (epilogue) {
+        case OCN_EPI_BF16: return launch5<OCN_EPI_BF16>(a, st);
+        case OCN_EPI_BIAS_GELU: return launch5<OCN_EPI_BIAS_GELU>(a, st);
+        case OCN_EPI_BIAS_RESID_F32: return launch5<OCN_EPI_BIAS_RESID_F32>(a, st);
+        case OCN_EPI_DGELU: return launch5<OCN_EPI_DGELU>(a, st);
+        case OCN_EPI_F32: return launch5<OCN_EPI_F32>(a, st);
+    }
+    return 1;
+}

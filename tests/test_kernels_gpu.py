@@ -117,14 +117,16 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     check(tag + " dgelu", out, ref * x.grad, bf16_out=True, abs_tol=1e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 640, 320), (2500, 768, 1024), (513, 1027, 96)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 640, 320), (2500, 768, 1024), (513, 1027, 96), (70000, 512, 256), (66000, 264, 128)])
 def test_gemm_nt_every_kernel_variant(dev, variant, M, N, K):
     """each NT tile geometry / pipeline (include/openclip_hip.h: ocn_set_gemm_variant) on ragged shapes, incl. a
     non-multiple-of-4 N (scalar epilogue path) and K = 96 (3 ring stages) / K = 64 (2 stages)"""
     from open_clip_amd import _lib, ops
-    if variant != 4 and K % 64:
+    if variant not in (4, 5) and K % 64:
         pytest.skip("two-stage kernels need K % 64 == 0")
+    if variant != 5 and M > 60000:
+        pytest.skip("multi-tile-per-workgroup shapes target the persistent kernel")
     g = torch.Generator().manual_seed(variant * 100 + M)
     a = bf(torch.randn(M, K, generator=g)).to(dev)
     b = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)

@@ -58,13 +58,15 @@ for name, M, N, K in SHAPES_NT:
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
         resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
         aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+        best = {v: 1e9 for v in variants}
+        for rnd in range(3):  # interleaved rounds, best-of (DVFS / cache state drifts between back-to-back variants)
+            for v in variants:
+                _lib.call("ocn_set_gemm_variant", v)
+                best[v] = min(best[v], timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux), iters=4))
         row = []
         for v in variants:
-            _lib.call("ocn_set_gemm_variant", v)
-            ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
-            tf = 2.0 * M * N * K / ms / 1e9
-            row.append(tf)
-            tot[v] += ms
+            row.append(2.0 * M * N * K / best[v] / 1e9)
+            tot[v] += best[v]
         print(f"{name:10s} {epi:3d} " + " ".join(f"{t:9.0f}" for t in row))
         del out, resid, aux
     del a, b
