@@ -85,40 +85,31 @@ __global__ void token_embed_fwd_kernel(const int64_t* __restrict__ text, const f
 __global__ void token_embed_bwd_kernel(const int64_t* __restrict__ text, const float* __restrict__ dx,
                                        float* __restrict__ dtable, float* __restrict__ dpos, int B, int L, int C, int vocab,
                                        int bchunk) {
-    // thread <-> (position l, 4 columns), loops over a chunk of the batch.  Rows that share a token at the same
-    // position (the zero padding behind EOT is ~half of all tokens) are run-length combined in registers before
-    // the fp32 atomics, which removes the hot-address serialisation on the pad row.
-    const int c4n = C / 4;
+    // thread <-> (position l, ONE column), loops over a chunk of the batch: a wave's atomic instruction then covers 256
+    // contiguous bytes of one table row (2 cache lines, fully used) instead of 4 bytes out of every 16 over 8 lines.
+    // Rows that share a token at the same position (SOT at l = 0, the zero padding behind EOT: about half of all
+    // tokens) are run-length combined in registers before the fp32 atomic, which removes the hot-address serialisation.
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= L * c4n) return;
-    const int l = idx / c4n, c = (idx % c4n) * 4;
+    if (idx >= L * C) return;
+    const int l = idx / C, c = idx % C;
     const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, run = {0.f, 0.f, 0.f, 0.f};
+    float acc = 0.f, run = 0.f;
     long run_tok = -1;
     for (int b = b0; b < b1; ++b) {
-        const f32x4 v = *(const f32x4*)(dx + ((size_t)b * L + l) * C + c);
-        acc = acc + v;
+        const float v = dx[((size_t)b * L + l) * C + c];
+        acc += v;
         long tok = text[(size_t)b * L + l];
         tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
         if (tok != run_tok) {
-            if (run_tok >= 0) {
-                float* d = dtable + (size_t)run_tok * C + c;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d + e, run[e]);
-            }
+            if (run_tok >= 0) unsafeAtomicAdd(dtable + (size_t)run_tok * C + c, run);
             run_tok = tok;
             run = v;
         } else {
-            run = run + v;
+            run += v;
         }
     }
-    if (run_tok >= 0) {
-        float* d = dtable + (size_t)run_tok * C + c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d + e, run[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dpos + (size_t)l * C + c + e, acc[e]);
+    if (run_tok >= 0) unsafeAtomicAdd(dtable + (size_t)run_tok * C + c, run);
+    unsafeAtomicAdd(dpos + (size_t)l * C + c, acc);
 }
 
 // ---- pooling ---------------------------------------------------------------------------------------
@@ -272,8 +263,8 @@ extern "C" int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* 
                                    int vocab, ocn_stream_t stream) {
     OCN_CHECK_ARG(text && dx && dtable && dpos, "ocn_token_embed_bwd: null operand");
     OCN_CHECK_ARG(B > 0 && L > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_bwd: bad shape");
-    const int bchunk = 128;
-    dim3 grid(ocn_cdiv((long)L * (C / 4), 256), ocn_cdiv(B, bchunk));
+    const int bchunk = 64;
+    dim3 grid(ocn_cdiv((long)L * C, 256), ocn_cdiv(B, bchunk));
     hipLaunchKernelGGL(token_embed_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, text, dx, dtable, dpos, B, L, C, vocab, bchunk);
     OCN_CHECK_LAUNCH("ocn_token_embed_bwd");
     return OCN_OK;

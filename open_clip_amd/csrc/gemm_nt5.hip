@@ -24,6 +24,8 @@
 
 namespace {
 
+__device__ long long g_nt5_trace[1024];  // developer timeline (DBG kernels only): 2 workgroups x 8 tiles x 8 stamps
+
 constexpr int UNIT = 16384;
 constexpr int RING_BYTES = 8 * UNIT;
 constexpr int STG_BYTES = 4096;
@@ -97,11 +99,9 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             bq[hb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + rd_chunk * 4) * 4, 0, 0));
     }
     // Every DMA issued so far must have landed: the first phases of the next tile then need no vmcnt wait and the
-    // stores below drain under them.  The wait is the BUILTIN (vmcnt(0), other counters untouched) so that hipcc's
-    // own scoreboard sees it: with LDS-DMA events it believes pending it turns every later load/store wait of the
-    // epilogue into vmcnt(0), i.e. one full memory round trip per store.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
+    // stores below drain under them.  (hipcc does not know about the asm LDS-DMAs; its own loads / stores below get
+    // ordinary counted waits.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int row_w = wm * 128;  // this wave's first row inside the tile
     if (BF16_STAGED) {
         constexpr int ROUNDS = (EPI == OCN_EPI_BIAS_GELU) ? 2 : 1;
@@ -215,98 +215,89 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         }
     }
 
-    // ---- DMA cursors: per-lane source pointers of this wave's two instructions per unit ----
-    const bf16* pA0[2];
-    const bf16* pA1[2];
-    const bf16* pB0[2];
-    const bf16* pB1[2];
-    int ab_i = 0, ab_kt = 0, a1_i = 0, a1_kt = 0;  // (tile ordinal, K-tile) each cursor issues next
+    // ---- DMA cursors ---------------------------------------------------------------------------------------------
+    // Operands are fetched with "buffer_load_dwordx4 ... lds" in INLINE ASM: (a) buffer addressing keeps the whole
+    // cursor in SGPRs (descriptor based at the tile's first row, K offset and row-block offset in soffset; rows beyond
+    // M / N read as zero) and leaves 4 lane-constant VGPR offsets instead of 8 advancing 64-bit pointers; (b) hipcc
+    // never sees an LDS-DMA, so the loads/stores of the epilogue get counted vmcnt waits (with a visible
+    // global_load_lds anywhere in the function every later wait degenerates to vmcnt(0)).
+    unsigned voA[2], voB[2];  // per-lane byte offsets of this wave's two pieces of an A / B unit (swizzled chunk included)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = (wave * 2 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz_nt(u);
+        voA[j] = (unsigned)(((u >> 6) * 128 + (u & 63)) * a.lda * 2 + c * 16);
+        voB[j] = (unsigned)(((u >> 5) * 64 + (u & 31)) * a.ldb * 2 + c * 16);
+    }
+    const unsigned a_half = (unsigned)(64 * a.lda * 2), b_half = (unsigned)(32 * a.ldb * 2);  // A1 - A0, B1 - B0 (bytes)
     auto tile_origin = [&](int i, int& m0, int& n0) {
         const int tile = xcd_remap((int)blockIdx.x + i * G, a.ntiles);
         m0 = (tile / a.tiles_n) * 256;
         n0 = (tile % a.tiles_n) * 256;
     };
+    auto make_desc = [&](const bf16* base, int row0, int rows, int ld) -> u32x4 {
+        long bytes = (long)(rows - row0) * ld * 2;
+        bytes = bytes > 0x7fffffffL ? 0x7fffffffL : bytes;
+        const unsigned long long p = (unsigned long long)(base + (size_t)row0 * ld);
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);
+        r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+        r[3] = 0x00020000u;
+        return r;
+    };
+    u32x4 dA1, dA0, dB;                            // descriptors of the tiles the two cursors are in
+    int ab_i = 0, a1_i = 0;                        // tile ordinal of each cursor
+    unsigned ab_k = 0, a1_k = 0;                   // byte offset of the K-tile each cursor issues next (kt * 128)
+    const unsigned k_end = (unsigned)nk * 128u;
     auto set_a1 = [&](int i) {
         int m0, n0;
         tile_origin(i, m0, n0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int u = (wave * 2 + j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz_nt(u);
-            int m = m0 + (u >> 6) * 128 + 64 + (u & 63);
-            m = m < a.M ? m : a.M - 1;
-            pA1[j] = a.A + (size_t)m * a.lda + c * 8;
-        }
+        dA1 = make_desc(a.A, m0, a.M, a.lda);
     };
     auto set_ab = [&](int i) {
         int m0, n0;
         tile_origin(i, m0, n0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int u = (wave * 2 + j) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz_nt(u);
-            int m = m0 + (u >> 6) * 128 + (u & 63);
-            m = m < a.M ? m : a.M - 1;
-            pA0[j] = a.A + (size_t)m * a.lda + c * 8;
-            int n = n0 + (u >> 5) * 64 + (u & 31);
-            int n1 = n + 32;
-            n = n < a.N ? n : a.N - 1;
-            n1 = n1 < a.N ? n1 : a.N - 1;
-            pB0[j] = a.B + (size_t)n * a.ldb + c * 8;
-            pB1[j] = a.B + (size_t)n1 * a.ldb + c * 8;
-        }
+        dA0 = make_desc(a.A, m0, a.M, a.lda);
+        dB = make_desc(a.B, n0, a.N, a.ldb);
     };
-    const int wave_dst = wave * 2048;  // this wave's 2 x 1 KiB pieces inside a unit
-#define DMA(PTR, J, SLOT)                                                        \
-    {                                                                            \
-        glds16(PTR[J], (OCN_LDS void*)(smem + (SLOT) + wave_dst + (J)*1024));    \
-        PTR[J] += 64;                                                            \
+    const unsigned wave_dst = lds_base + wave * 2048;  // this wave's 2 x 1 KiB pieces inside a unit
+    // one LDS-DMA piece: 64 lanes x 16 B from desc[voff + soff] to LDS m0 + lane*16 (m0 is compiler-reserved: save / restore)
+#define DMA(DESC, VOFF, SOFF, SLOT, J)                                                                         \
+    {                                                                                                          \
+        unsigned keep_;                                                                                        \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_)                                                                            \
+                     : "v"(VOFF[J]), "s"(DESC), "s"(wave_dst + (SLOT) + (J)*1024), "s"(SOFF)                    \
+                     : "memory");                                                                              \
     }
     auto adv_a1 = [&]() {
-        if (++a1_kt == nk) {
-            a1_kt = 0;
-            if (a1_i + 1 < my_tiles) {
-                ++a1_i;
-                set_a1(a1_i);
-            } else {  // nothing left: keep re-fetching the last tile (valid addresses, results unused)
-                pA1[0] -= (size_t)nk * 64;
-                pA1[1] -= (size_t)nk * 64;
-            }
+        a1_k += 128;
+        if (a1_k == k_end) {
+            a1_k = 0;
+            if (a1_i + 1 < my_tiles) set_a1(++a1_i);  // else: keep re-fetching the last tile (valid addresses, results unused)
         }
     };
     auto adv_ab = [&]() {
-        if (++ab_kt == nk) {
-            ab_kt = 0;
-            if (ab_i + 1 < my_tiles) {
-                ++ab_i;
-                set_ab(ab_i);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    pA0[j] -= (size_t)nk * 64;
-                    pB0[j] -= (size_t)nk * 64;
-                    pB1[j] -= (size_t)nk * 64;
-                }
-            }
+        ab_k += 128;
+        if (ab_k == k_end) {
+            ab_k = 0;
+            if (ab_i + 1 < my_tiles) set_ab(++ab_i);
         }
     };
+#define DMA_A1(J, P) DMA(dA1, voA, a1_k + a_half, A_SLOT(1, P), J)
+#define DMA_A0(J, P) DMA(dA0, voA, ab_k, A_SLOT(0, P), J)
+#define DMA_B0(J, P) DMA(dB, voB, ab_k, B_SLOT(0, P), J)
+#define DMA_B1(J, P) DMA(dB, voB, ab_k + b_half, B_SLOT(1, P), J)
 
-    if (a.ablate & 1024) {  // EXPERIMENT: skew the workgroups over one tile period so that epilogue store bursts do not coincide
-        const int slot = (((int)blockIdx.x >> 3) * 13) & 31;                 // spread the CUs of an XCD over 32 slots
-        const long long wait = (long long)slot * (nk * 200 + 300) / 32;      // wall-clock ticks (100 MHz); tile ~ nk*2us + 3us
-        const long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     // ---- prologue: K-tiles 0 and 1 (minus A1(1)) ----
     set_ab(0);
     set_a1(0);
-    DMA(pA0, 0, A_SLOT(0, 0)) DMA(pA0, 1, A_SLOT(0, 0)) DMA(pB0, 0, B_SLOT(0, 0)) DMA(pB0, 1, B_SLOT(0, 0))
-    DMA(pB1, 0, B_SLOT(1, 0)) DMA(pB1, 1, B_SLOT(1, 0))
+    DMA_A0(0, 0) DMA_A0(1, 0) DMA_B0(0, 0) DMA_B0(1, 0) DMA_B1(0, 0) DMA_B1(1, 0)
     adv_ab();
-    DMA(pA1, 0, A_SLOT(1, 0)) DMA(pA1, 1, A_SLOT(1, 0))
+    DMA_A1(0, 0) DMA_A1(1, 0)
     adv_a1();
-    DMA(pA0, 0, A_SLOT(0, 1)) DMA(pA0, 1, A_SLOT(0, 1)) DMA(pB0, 0, B_SLOT(0, 1)) DMA(pB0, 1, B_SLOT(0, 1))
-    DMA(pB1, 0, B_SLOT(1, 1)) DMA(pB1, 1, B_SLOT(1, 1))
+    DMA_A0(0, 1) DMA_A0(1, 1) DMA_B0(0, 1) DMA_B0(1, 1) DMA_B1(0, 1) DMA_B1(1, 1)
     adv_ab();
 
     f32x16 acc[2][2][2];  // [A half][32-row sub-block][B half], each a 32x32 C^T tile
@@ -325,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 #define RD_B(KS, P) DSR(fb[0][KS], vb[KS], B_RD(0, P)); DSR(fb[1][KS], vb[KS], B_RD(1, P));
 
     // one K-tile held in ring parity P; SKIP: the epilogue (or prologue) before it already drained every DMA
+    // (Measured, no effect: issuing the DMA pieces of the two waves that share a SIMD in different k-substeps.)
 #define KTILE(P, SKIP, LAST)                                                                          \
     {                                                                                             \
         /* ---- even phase: A0 x (B0, B1) ---- */                                                 \
@@ -335,9 +327,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         SB();                                                                                     \
         acc[0][0][0] = mfma32(fb[0][0], fa[0][0], acc[0][0][0]);                                  \
         acc[0][0][1] = mfma32(fb[1][0], fa[0][0], acc[0][0][1]);                                  \
-        DMA(pA1, 0, A_SLOT(1, (P) ^ 1))                                                           \
+        DMA_A1(0, (P) ^ 1)                                                                        \
         acc[0][1][0] = mfma32(fb[0][0], fa[0][1], acc[0][1][0]);                                  \
-        DMA(pA1, 1, A_SLOT(1, (P) ^ 1))                                                           \
+        DMA_A1(1, (P) ^ 1)                                                                        \
         acc[0][1][1] = mfma32(fb[1][0], fa[0][1], acc[0][1][1]);                                  \
         SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 2, 0, P) RD_B(2, P)                                                           \
@@ -360,20 +352,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         RD_A(fa[1], 1, 1, P)                                                                      \
         SB();                                                                                     \
         acc[1][0][0] = mfma32(fb[0][0], fa[0][0], acc[1][0][0]);                                  \
-        DMA(pA0, 0, A_SLOT(0, P))                                                                 \
+        DMA_A0(0, P)                                                                              \
         acc[1][0][1] = mfma32(fb[1][0], fa[0][0], acc[1][0][1]);                                  \
-        DMA(pA0, 1, A_SLOT(0, P))                                                                 \
+        DMA_A0(1, P)                                                                              \
         acc[1][1][0] = mfma32(fb[0][0], fa[0][1], acc[1][1][0]);                                  \
-        DMA(pB0, 0, B_SLOT(0, P))                                                                 \
+        DMA_B0(0, P)                                                                              \
         acc[1][1][1] = mfma32(fb[1][0], fa[0][1], acc[1][1][1]);                                  \
-        DMA(pB0, 1, B_SLOT(0, P))                                                                 \
+        DMA_B0(1, P)                                                                              \
         SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 2, 1, P)                                                                      \
         SB();                                                                                     \
         acc[1][0][0] = mfma32(fb[0][1], fa[1][0], acc[1][0][0]);                                  \
-        DMA(pB1, 0, B_SLOT(1, P))                                                                 \
+        DMA_B1(0, P)                                                                              \
         acc[1][0][1] = mfma32(fb[1][1], fa[1][0], acc[1][0][1]);                                  \
-        DMA(pB1, 1, B_SLOT(1, P))                                                                 \
+        DMA_B1(1, P)                                                                              \
         acc[1][1][0] = mfma32(fb[0][1], fa[1][1], acc[1][1][0]);                                  \
         acc[1][1][1] = mfma32(fb[1][1], fa[1][1], acc[1][1][1]);                                  \
         SB(); LGKM0(); SB();                                                                      \
@@ -391,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 
     const unsigned stg = lds_base + RING_BYTES + wave * STG_BYTES;
     long long* dbg = nullptr;
-    if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = (long long*)a.aux + (blockIdx.x ? 512 : 0);
+    if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = g_nt5_trace + (blockIdx.x ? 512 : 0);
 #define STAMP(IDX) if (DBG && dbg && i < 8) dbg[i * 8 + (IDX)] = wall_clock64();
     for (int i = 0; i < my_tiles; ++i) {
         STAMP(0)
@@ -425,6 +417,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 #undef RD_A
 #undef RD_B
 #undef DMA
+#undef DMA_A1
+#undef DMA_A0
+#undef DMA_B0
+#undef DMA_B1
 }
 
 int g_num_cu = 0;
@@ -440,13 +436,13 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.tiles_n = ocn_cdiv(a.N, 256);
     a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
     const int grid = a.ntiles < g_num_cu ? a.ntiles : g_num_cu;
-    if ((a.ablate & 64) && EPI == OCN_EPI_BF16) {  // developer build (ablations / timeline), plain bf16 epilogue only
+    if (a.ablate & 64) {  // developer build: per-tile timeline into a side buffer passed in a.resid/a.aux (tools/gemm_trace.py)
         static bool dbg_attr_set = false;
         if (!dbg_attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<OCN_EPI_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             dbg_attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_nt5_kernel<OCN_EPI_BF16, true>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_nt5_kernel<EPI, true>), dim3(grid), dim3(512), LDS_BYTES, st, a);
         OCN_CHECK_LAUNCH("ocn_gemm_nt");
         return OCN_OK;
     }
@@ -461,6 +457,10 @@ int launch5(GemmNtArgs a, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int ocn_debug_nt5_trace(long long* host_out /*[1024]*/) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt5_trace), sizeof(long long) * 1024) == hipSuccess ? OCN_OK : OCN_ERR_LAUNCH;
+}
 
 int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
     // needs whole 128-k pairs of K-tiles, 16-byte aligned bf16 rows on the output side and vector-width columns
