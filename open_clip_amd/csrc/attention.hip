@@ -10,6 +10,10 @@
 // exchange, and the C-layout registers of S^T are directly the B operand of the second product
 // (k-slot (h,e) of step t <-> accumulator register 8t+e <-> key 32kb + 16t + 8(e>>2) + 4h + (e&3)).
 // Softmax in fp32 (exp2 domain); the causal mask of the text tower is a predicate, not a tensor.
+// Global traffic is full 128-byte lines both ways: every input tile arrives by LDS-DMA, and every output tile (O, dQ, dK,
+// dV) is transposed through LDS (the wave's own rows of an input image it no longer needs) and leaves as 16-byte stores
+// covering 8 whole rows per instruction -- a row-per-lane epilogue of 8-byte pieces is store-ISSUE bound (32 partial
+// lines per instruction; MI355X_MICROARCH.md "attention epilogue store tail").
 #include "ocn_common.h"
 
 namespace {
@@ -62,6 +66,30 @@ OCN_DEV f32x16 zero16() {
     return z;
 }
 
+// A wave's 32 x 64 result tile (a0: d 0..31, a1: d 32..63; lane <-> row lr, registers 4*q4.. <-> d = 8*q4 + 4*lh ..) goes to
+// rows [row0, row0+32) of the LDS image `img` (16-byte chunks XOR-swizzled by row & 7), then out as whole rows.
+// Only this wave touches those image rows from here on.
+OCN_DEV void stage_tile(char* img, int row0, int lane, const f32x16& a0, const f32x16& a1, float mul) {
+    const int lr = lane & 31, lh = lane >> 5;
+    char* rowp = img + (row0 + lr) * 128 + lh * 8;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const bf16x4 v0 = {f2bf(a0[4 * q4] * mul), f2bf(a0[4 * q4 + 1] * mul), f2bf(a0[4 * q4 + 2] * mul), f2bf(a0[4 * q4 + 3] * mul)};
+        const bf16x4 v1 = {f2bf(a1[4 * q4] * mul), f2bf(a1[4 * q4 + 1] * mul), f2bf(a1[4 * q4 + 2] * mul), f2bf(a1[4 * q4 + 3] * mul)};
+        *(bf16x4*)(rowp + ((q4 ^ (lr & 7)) << 4)) = v0;
+        *(bf16x4*)(rowp + (((4 + q4) ^ (lr & 7)) << 4)) = v1;
+    }
+}
+OCN_DEV void flush_tile(const char* img, int row0, int lane, bf16* base, size_t row_stride, int L) {
+    const int r8 = lane >> 3, c = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 8 + r8;
+        const bf16x8 v = *(const bf16x8*)(img + row * 128 + ((c ^ (row & 7)) << 4));
+        if (row < L) *(bf16x8*)(base + (size_t)row * row_stride + c * 8) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -77,21 +105,22 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
     const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
-    char* sK = smem;
-    char* sV = smem + LP * 128;
+    char* sQ = smem;
+    char* sK = smem + LP * 128;
+    char* sV = smem + 2 * LP * 128;
+    stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
     stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
     stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
 
     const int qb = wave;
     const int lr = lane & 31, lh = lane >> 5;
     const int query = qb * 32 + lr;
-    const int qrow = query < L ? query : L - 1;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qbase + (size_t)qrow * rs + s * 16 + lh * 8);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = frag_rows(sQ, query, s, lane);  // rows >= L are copies of row L-1 (stage_head clamps)
 
     const float sc = scale * LOG2E;
     float m = -1e30f, l = 0.f;
@@ -134,36 +163,15 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (query < L) {
-        bf16* orow = out + ((size_t)b * L + query) * C + hd * 64;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int d = 8 * q4 + 4 * lh;
-            bf16x4 v0 = {f2bf(o0[4 * q4] * inv), f2bf(o0[4 * q4 + 1] * inv), f2bf(o0[4 * q4 + 2] * inv), f2bf(o0[4 * q4 + 3] * inv)};
-            bf16x4 v1 = {f2bf(o1[4 * q4] * inv), f2bf(o1[4 * q4 + 1] * inv), f2bf(o1[4 * q4 + 2] * inv), f2bf(o1[4 * q4 + 3] * inv)};
-            *(bf16x4*)(orow + d) = v0;
-            *(bf16x4*)(orow + 32 + d) = v1;
-        }
-        if (lh == 0) lse[((size_t)b * H + hd) * L + query] = (m + log2f(l)) * LN2;
-    }
+    // O goes out through this wave's own (already consumed) rows of the Q image
+    stage_tile(sQ, qb * 32, lane, o0, o1, inv);
+    flush_tile(sQ, qb * 32, lane, out + (size_t)b * L * C + hd * 64, (size_t)C, L);
+    if (query < L && lh == 0) lse[((size_t)b * H + hd) * L + query] = (m + log2f(l)) * LN2;
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-OCN_DEV void store_t(bf16* base, size_t row_stride, int row, int L, int lh, const f32x16& a0, const f32x16& a1) {
-    if (row >= L) return;
-    bf16* p = base + (size_t)row * row_stride;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-        const int d = 8 * q4 + 4 * lh;
-        bf16x4 v0 = {f2bf(a0[4 * q4]), f2bf(a0[4 * q4 + 1]), f2bf(a0[4 * q4 + 2]), f2bf(a0[4 * q4 + 3])};
-        bf16x4 v1 = {f2bf(a1[4 * q4]), f2bf(a1[4 * q4 + 1]), f2bf(a1[4 * q4 + 2]), f2bf(a1[4 * q4 + 3])};
-        *(bf16x4*)(p + d) = v0;
-        *(bf16x4*)(p + 32 + d) = v1;
-    }
-}
-
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
     const float sc = scale * LOG2E;
 
     // ---- phase A: dQ for query block `wave` (lane <-> query, registers <-> keys) ----
+    f32x16 dq0 = zero16(), dq1 = zero16();
     {
         const int qb = wave;
         const int query = qb * 32 + lr;
@@ -223,7 +232,6 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
             qf[s] = frag_rows(sQ, query, s, lane);
             dof[s] = frag_rows(sdO, query, s, lane);
         }
-        f32x16 dq0 = zero16(), dq1 = zero16();
         const int nkb = causal ? qb + 1 : nwaves;
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16 st = zero16(), dp = zero16();
@@ -246,7 +254,6 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
                 dq1 = mfma32(frag_cols(sK, kb * 32, t, 1, lane), dsf, dq1);
             }
         }
-        store_t(dqkv + (size_t)b * L * rs + hd * 64, rs, query, L, lh, dq0, dq1);
     }
 
     // ---- phase B: dK, dV for key block `wave` (lane <-> key, registers <-> queries) ----
@@ -259,6 +266,12 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
             kf[s] = frag_rows(sK, key, s, lane);
             vf[s] = frag_rows(sV, key, s, lane);
         }
+        // every wave has finished phase A and holds its K / V fragments: the K image is free -> dQ leaves through it now
+        // (keeping dQ in registers across phase B would cost the second wave per SIMD)
+        __syncthreads();
+        bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
+        stage_tile(sK, wave * 32, lane, dq0, dq1, 1.0f);
+        flush_tile(sK, wave * 32, lane, dbase, rs, L);
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
         const int qb0 = causal ? kb : 0;
         for (int qb = qb0; qb < nwaves; ++qb) {
@@ -285,9 +298,12 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
                 dk1 = mfma32(frag_cols(sQ, qb * 32, t, 1, lane), dsf, dk1);
             }
         }
-        bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
-        store_t(dbase + C, rs, key, L, lh, dk0, dk1);
-        store_t(dbase + 2 * C, rs, key, L, lh, dv0, dv1);
+        // every wave is done with the Q / dO images: they become the transposing buffers of dK / dV
+        __syncthreads();
+        stage_tile(sQ, wave * 32, lane, dk0, dk1, 1.0f);
+        stage_tile(sdO, wave * 32, lane, dv0, dv1, 1.0f);
+        flush_tile(sQ, wave * 32, lane, dbase + C, rs, L);
+        flush_tile(sdO, wave * 32, lane, dbase + 2 * C, rs, L);
     }
 }
 
@@ -304,7 +320,7 @@ extern "C" int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L
     OCN_CHECK_ARG(qkv && out && lse, "ocn_attn_fwd: null operand");
     if (int e = check_attn("ocn_attn_fwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
-    const int lds = 2 * nw * 32 * 128;
+    const int lds = 3 * nw * 32 * 128;
     if (nw <= 4) {
         hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
                            (bf16*)out, lse, L, H, causal, scale);

@@ -418,15 +418,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs a) {
 // ------------------------------------------------------------------------------------------------
 // TN: dW[n,k] += alpha * sum_m A[m,n] * B[m,k]
 // ------------------------------------------------------------------------------------------------
-struct GemmTnArgs {
-    const bf16* A;
-    const bf16* B;
-    float* dW;
-    float* dbias;
-    int lda, ldb, ldw, M, N, K;
-    float alpha;
-    int tiles_n, tiles_k, chunk, nwg;
-};
 
 // rows [m_base, m_base+64) (zero beyond m_end) x cols [col0, col0+128) -> LDS tile of 64 rows x 256 B
 OCN_DEV void stage_tn(const bf16* __restrict__ G, int ld, int m_base, int m_end, int col0, int ncols, char* sT, int wave,
@@ -707,7 +698,7 @@ int launch_nt_geo(GemmNtArgs a, hipStream_t st) {
     return OCN_OK;
 }
 
-int g_tn_variant = 0;  // 0 = auto, 1 = 128x128 two-stage, 2 = 256x256 ring
+int g_tn_variant = 0;  // 0 = auto, 1 = 128x128 two-stage, 2 = 256x256 ring, 3 = 256x256 hand-scheduled (gemm_tn5.hip)
 int g_nt_ablate = 0;
 int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128, 4 = 256x256 4-stage ring (K % 32), 5 = persistent 256x256 (K % 128)
 
@@ -787,7 +778,13 @@ extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb,
     GemmTnArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.dW = dW; a.dbias = dbias;
     a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    const bool ring = (g_tn_variant == 2) || (g_tn_variant == 0 && (long)M * N * K >= (1L << 31) && N >= 256 && K >= 256);
+    const bool big = (long)M * N * K >= (1L << 31) && N >= 256 && K >= 256;
+    if (g_tn_variant == 3 || (g_tn_variant == 0 && big)) {  // hand-scheduled 256x256 kernel (gemm_tn5.hip); falls through if the shape does not fit it
+        const int rc = ocn_launch_tn5(a, (hipStream_t)stream);
+        if (rc < 0) ocn_set_error("ocn_gemm_tn_accum: launch failed");
+        if (rc <= 0) return rc;
+    }
+    const bool ring = (g_tn_variant == 2) || (g_tn_variant == 0 && big);
     const int T = ring ? 256 : 128, RS = ring ? 32 : 64;
     a.tiles_n = ocn_cdiv(N, T);
     a.tiles_k = ocn_cdiv(K, T);

@@ -22,3 +22,16 @@ OCN_DEV int swz_nt(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 // persistent 256x256 NT kernel (gemm_nt5.hip); returns 1 if the shape is not supported by it (caller falls back)
 int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st);
+
+struct GemmTnArgs {
+    const bf16* A;
+    const bf16* B;
+    float* dW;
+    float* dbias;
+    int lda, ldb, ldw, M, N, K;
+    float alpha;
+    int tiles_n, tiles_k, chunk, nwg;
+};
+
+// hand-scheduled 256x256 TN (wgrad) kernel (gemm_tn5.hip); returns 1 if the shape is not supported by it (caller falls back)
+int ocn_launch_tn5(GemmTnArgs a, hipStream_t st);

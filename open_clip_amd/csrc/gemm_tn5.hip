@@ -1,0 +1,290 @@
+// Hand-scheduled TN (weight-gradient) GEMM for gfx950:  dW[n,k] += alpha * sum_m A[m,n] * B[m,k]  (+ dbias[n] += alpha * sum_m A[m,n]).
+//
+// Same geometry as gemm_tn_ring_kernel (gemm.hip): a 256 (n) x 256 (k) tile of dW per workgroup, 8 waves (2 x 4, wave tile
+// 128 x 64 = 4 x 2 MFMA blocks), 32 reduction rows per step, 4-slot LDS ring (4 x 32 KiB: [32 m][256 n] of A and
+// [32 m][256 k] of B as 512-byte rows, 16-byte chunks XOR-swizzled by (row & 3) << 2 on the SOURCE address), split over M so
+// that one launch fills the chip; fp32 atomics into dW.  What changed, and why (disassembly of the ring kernel):
+//   * with compiler-visible global_load_lds + ds_read_tr builtins hipcc waits vmcnt(0) before the fragment reads of every
+//     step (it cannot prove the reads do not alias an in-flight LDS-DMA), so the "3 stages ahead" ring never ran ahead.
+//     Here the LDS-DMA is an inline-asm "buffer_load_dwordx4 ... lds" and the transposing fragment reads are inline-asm
+//     ds_read_b64_tr_b16, with ONE counted vmcnt(4) and one raw s_barrier per step;
+//   * buffer descriptors are based at the split's first row with num_records = the split's bytes: reduction rows beyond
+//     m_end and (offset forced out of range) columns beyond N / K read as ZERO in hardware -> no per-DMA select, no tail code
+//     (steps beyond the split's last row multiply zeros);
+//   * the bias gradient (column sums of A by an MFMA against ones) is time-sliced over the tiles_k workgroups that share an
+//     A strip: workgroup tk does it on steps kt == tk (mod tiles_k), so every workgroup carries the same 1/(8 tiles_k) extra
+//     MFMA work instead of one workgroup in tiles_k carrying 1/8.
+// Step kt (stage kt lives in ring slot kt & 3; X = fragments of sub-step 0, Y = sub-step 1):
+//   wait vmcnt(4) [own DMAs of stage kt+1 landed] -> s_barrier [everybody's landed; everybody finished reading stage kt-1]
+//   issue reads Y(kt) | 8 MFMAs on X(kt) with the 4 DMA pieces of stage kt+3 (into the slot of stage kt-1) between them
+//   wait lgkmcnt(0) | issue reads X(kt+1) | 8 MFMAs on Y(kt) | wait lgkmcnt(0)
+#include "gemm_args.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int STAGE = 32768, HALF = 16384, LDS_BYTES = 4 * STAGE;
+
+struct Frag {
+    u32x2 lo, hi;  // m rows {0..3} and {4..7} of this lane's 8 reduction slots
+};
+struct FragSet {
+    Frag a[4], b[2];
+};
+
+OCN_DEV bf16x8 cat(const Frag& f) {
+    const u32x4 v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// two transposing reads (rows r..r+3 and r+4..r+7) of one 32-wide block; early-clobber: the address is read twice
+#define TRR(F, ADDR, OFF)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"          \
+                 : "=&v"((F).lo), "=&v"((F).hi)                                                        \
+                 : "v"(ADDR), "i"(OFF), "i"((OFF) + 2048))
+// the wait names every destination "+v": the compiler cannot copy / combine a fragment before its data has landed
+#define WAIT_SET(S)                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
+                 : "+v"((S).a[0].lo), "+v"((S).a[0].hi), "+v"((S).a[1].lo), "+v"((S).a[1].hi), "+v"((S).a[2].lo),          \
+                   "+v"((S).a[2].hi), "+v"((S).a[3].lo), "+v"((S).a[3].hi), "+v"((S).b[0].lo), "+v"((S).b[0].hi),          \
+                   "+v"((S).b[1].lo), "+v"((S).b[1].hi))
+
+template <bool BIAS>
+__global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = xcd_remap(blockIdx.x, a.nwg);
+    const int ntile = a.tiles_n * a.tiles_k;
+    const int split = wid / ntile, tile = wid % ntile;
+    const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int m_begin = split * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int rows = m_end - m_begin;
+    const int nk = (rows + 31) / 32;
+    const int wn = wave >> 2, wk = wave & 3;
+    const unsigned lds_base = (unsigned)(size_t)(OCN_LDS char*)smem;
+
+    // ---- descriptors: based at the split's first row; everything past its last row reads as zero -------------------------
+    auto make_desc = [&](const bf16* base, int ld) -> u32x4 {
+        const unsigned long long p = (unsigned long long)(base + (size_t)m_begin * ld);
+        const long bytes = (long)rows * ld * 2;  // < 2^31 (checked by the launcher)
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);
+        r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+        r[3] = 0x00020000u;
+        return r;
+    };
+    const u32x4 dA = make_desc(a.A, a.lda), dB = make_desc(a.B, a.ldb);
+
+    // ---- DMA: wave w moves rows {2w, 2w+1} (piece 0) and {16+2w, 17+2w} (piece 1) of each operand's [32][256] stage image ---
+    unsigned voA[2], voB[2];  // per-lane byte offsets into the descriptors (advance by 32 rows per step)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + j * 8) * 2 + (lane >> 5);
+        const int c = ((lane & 31) ^ ((r & 3) << 2)) * 8;  // source-side chunk swizzle
+        voA[j] = (n0 + c) < a.N ? (unsigned)(r * a.lda + n0 + c) * 2u : 0x80000000u;  // out-of-range columns stay out of range
+        voB[j] = (k0 + c) < a.K ? (unsigned)(r * a.ldb + k0 + c) * 2u : 0x80000000u;
+    }
+    const unsigned stepA = (unsigned)(32 * a.lda * 2), stepB = (unsigned)(32 * a.ldb * 2);
+    const unsigned wave_dst = lds_base + wave * 1024;
+    // one LDS-DMA piece: 64 lanes x 16 B from desc[voff] to LDS m0 + lane*16 (m0 is compiler-reserved: save / restore)
+#define DMA(DESC, VOFF, DST)                                                                                              \
+    {                                                                                                                     \
+        unsigned keep_;                                                                                                   \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_)                                                                                       \
+                     : "v"(VOFF), "s"(DESC), "s"(DST)                                                                     \
+                     : "memory");                                                                                         \
+    }
+#define DMA_A(J, SLOT) DMA(dA, voA[J], wave_dst + (SLOT) * STAGE + (J) * 8192)
+#define DMA_B(J, SLOT) DMA(dB, voB[J], wave_dst + (SLOT) * STAGE + HALF + (J) * 8192)
+#define DMA_ADV()      \
+    {                  \
+        voA[0] += stepA; \
+        voA[1] += stepA; \
+        voB[0] += stepB; \
+        voB[1] += stepB; \
+    }
+
+    // ---- fragment read addresses -----------------------------------------------------------------------------------------
+    // 16-lane group: 4 rows x 16 columns; lane i passes the address of columns (i&3)*4.. of row i>>2 and receives column i.
+    // byte = row * 512 + (chunk ^ ((row & 3) << 2)) * 16 + (i & 1) * 8, row = s*16 + h*8 + (i>>2) (+4), chunk = col/8 + (i&3)>>1.
+    // acc index ib of this wave is A block (ib + wk) & 3 (so that block wk, the one this wave sums for dbias, is a[0]).
+    unsigned vaL[4], vbL[2], vaH[4], vbH[2];  // ring slots 0-1 / 2-3 (ds offsets are 16 bits)
+    {
+        const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5, i2 = i >> 2;
+        const unsigned lane_off = (unsigned)((h * 8 + i2) * 512 + (2 * g + ((i & 3) >> 1)) * 16 + (i & 1) * 8);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const int blk = (ib + wk) & 3;
+            vaL[ib] = lds_base + lane_off + (unsigned)((wn * 16 + ((blk ^ i2) << 2)) * 16);
+            vaH[ib] = vaL[ib] + 65536u;
+        }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            vbL[jb] = lds_base + lane_off + (unsigned)((((wk * 2 + jb) ^ i2) << 2) * 16);
+            vbH[jb] = vbL[jb] + 65536u;
+        }
+    }
+#define READ_SET(S, SLOT, SUB)                                                                       \
+    {                                                                                                \
+        constexpr int o_ = ((SLOT) & 1) * STAGE + (SUB) * 8192;                                       \
+        TRR((S).a[0], ((SLOT) < 2 ? vaL[0] : vaH[0]), o_);                                            \
+        TRR((S).b[0], ((SLOT) < 2 ? vbL[0] : vbH[0]), o_ + HALF);                                     \
+        TRR((S).b[1], ((SLOT) < 2 ? vbL[1] : vbH[1]), o_ + HALF);                                     \
+        TRR((S).a[1], ((SLOT) < 2 ? vaL[1] : vaH[1]), o_);                                            \
+        TRR((S).a[2], ((SLOT) < 2 ? vaL[2] : vaH[2]), o_);                                            \
+        TRR((S).a[3], ((SLOT) < 2 ? vaL[3] : vaH[3]), o_);                                            \
+    }
+
+    f32x16 acc[4][2], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    int bc = tk;  // steps until this workgroup's next bias step
+
+    // ---- prologue: stages 0, 1, 2 ------------------------------------------------------------------------------------------
+    DMA_A(0, 0) DMA_A(1, 0) DMA_B(0, 0) DMA_B(1, 0)
+    DMA_ADV()
+    DMA_A(0, 1) DMA_A(1, 1) DMA_B(0, 1) DMA_B(1, 1)
+    DMA_ADV()
+    DMA_A(0, 2) DMA_A(1, 2) DMA_B(0, 2) DMA_B(1, 2)
+    DMA_ADV()
+    FragSet X, Y;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SB();
+    READ_SET(X, 0, 0)
+    WAIT_SET(X);
+    SB();
+
+#define MM(S, IB, JB) acc[IB][JB] = mfma32(cat((S).a[IB]), cat((S).b[JB]), acc[IB][JB]);
+#define STEP(SLOT)                                                                                   \
+    {                                                                                                \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                \
+        SB();                                                                                        \
+        READ_SET(Y, SLOT, 1)                                                                         \
+        SB();                                                                                        \
+        const bool bias_now = BIAS && (bc == 0);                                                     \
+        MM(X, 0, 0) MM(X, 0, 1)                                                                      \
+        SB();                                                                                        \
+        DMA_A(0, ((SLOT) + 3) & 3)                                                                   \
+        SB();                                                                                        \
+        MM(X, 1, 0) MM(X, 1, 1)                                                                      \
+        SB();                                                                                        \
+        DMA_A(1, ((SLOT) + 3) & 3)                                                                   \
+        SB();                                                                                        \
+        MM(X, 2, 0) MM(X, 2, 1)                                                                      \
+        SB();                                                                                        \
+        DMA_B(0, ((SLOT) + 3) & 3)                                                                   \
+        SB();                                                                                        \
+        MM(X, 3, 0) MM(X, 3, 1)                                                                      \
+        SB();                                                                                        \
+        DMA_B(1, ((SLOT) + 3) & 3)                                                                   \
+        if (bias_now) accb = mfma32(cat(X.a[0]), ones, accb);                                        \
+        SB();                                                                                        \
+        WAIT_SET(Y);                                                                                 \
+        SB();                                                                                        \
+        READ_SET(X, ((SLOT) + 1) & 3, 0)                                                             \
+        SB();                                                                                        \
+        MM(Y, 0, 0) MM(Y, 0, 1) MM(Y, 1, 0) MM(Y, 1, 1)                                              \
+        DMA_ADV()                                                                                    \
+        MM(Y, 2, 0) MM(Y, 2, 1) MM(Y, 3, 0) MM(Y, 3, 1)                                              \
+        if (bias_now) accb = mfma32(cat(Y.a[0]), ones, accb);                                        \
+        if (BIAS) bc = (bc == 0 ? a.tiles_k : bc) - 1;                                               \
+        SB();                                                                                        \
+        WAIT_SET(X);                                                                                 \
+        SB();                                                                                        \
+    }
+    // nk is rounded up to whole groups of 4 steps: the surplus steps see all-zero stages (reads past the split's last row)
+    for (int kt = 0; kt < nk; kt += 4) {
+        STEP(0)
+        STEP(1)
+        STEP(2)
+        STEP(3)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (zero-fill) DMAs must land before the LDS is released
+#undef STEP
+#undef MM
+#undef READ_SET
+#undef DMA_ADV
+#undef DMA_A
+#undef DMA_B
+#undef DMA
+
+    // ---- epilogue: fp32 atomics (lanes of a half-wave hit 32 consecutive k = one 128-byte line) ---------------------------
+    const int lr = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int blk = (i + wk) & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gk = k0 + wk * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gn = n0 + wn * 128 + blk * 32 + mfma32_row(r, lane);
+                if (gn < a.N && gk < a.K) unsafeAtomicAdd(a.dW + (size_t)gn * a.ldw + gk, a.alpha * acc[i][j][r]);
+            }
+        }
+    }
+    if (BIAS && lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gn = n0 + wn * 128 + wk * 32 + mfma32_row(r, lane);
+            if (gn < a.N) unsafeAtomicAdd(a.dbias + gn, a.alpha * accb[r]);
+        }
+    }
+}
+
+int g_tn5_num_cu = 0;
+
+}  // namespace
+
+int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
+    if (a.N % 8 || a.K % 8 || a.lda % 8 || a.ldb % 8) return 1;
+    if (g_tn5_num_cu == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_tn5_num_cu = n;
+    }
+    a.tiles_n = ocn_cdiv(a.N, 256);
+    a.tiles_k = ocn_cdiv(a.K, 256);
+    const int ntile = a.tiles_n * a.tiles_k;
+    const int msteps = ocn_cdiv(a.M, 32);
+    int splits = g_tn5_num_cu / ntile;  // one workgroup per CU
+    if (splits < 1) splits = 1;
+    if (splits > msteps) splits = msteps;
+    a.chunk = ocn_cdiv(msteps, splits) * 32;
+    splits = ocn_cdiv(a.M, a.chunk);
+    a.nwg = splits * ntile;
+    const long ldmax = a.lda > a.ldb ? a.lda : a.ldb;
+    if ((long)(a.chunk + 128) * ldmax * 2 >= 0x7fffffffL) return 1;  // 32-bit buffer offsets (incl. the run-ahead past m_end)
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    if (hipGetLastError() != hipSuccess) return OCN_ERR_LAUNCH;
+    return OCN_OK;
+}

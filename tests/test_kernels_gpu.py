@@ -152,8 +152,8 @@ def test_gemm_nt_every_kernel_variant(dev, variant, M, N, K):
         _lib.call("ocn_set_gemm_variant", 0)
 
 
-@pytest.mark.parametrize("tv", [1, 2])
-@pytest.mark.parametrize("M,N,K", [(3000, 640, 328), (100, 264, 520), (40000, 512, 256)])
+@pytest.mark.parametrize("tv", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(3000, 640, 328), (100, 264, 520), (40000, 512, 256), (9 * 50, 768, 3072), (20011, 1536, 512)])
 def test_gemm_tn_every_kernel_variant(dev, tv, M, N, K):
     from open_clip_amd import _lib, ops
     g = torch.Generator().manual_seed(tv * 10 + M)

@@ -15,7 +15,7 @@ SHAPES_NT = [  # (name, M, N, K)
     ("txt qkv", Mt, 1536, 512), ("txt out", Mt, 512, 512), ("txt fc", Mt, 2048, 512), ("txt proj", Mt, 512, 2048),
 ]
 # variant ids may carry a developer ablation mask in bits 8+: 4 + 256*mask
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3".split(","))]
+variants = [] if (len(sys.argv) > 1 and sys.argv[1] == "-") else [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3".split(","))]  # "-" = skip the NT sweep
 epis = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3".split(","))]
 
 
@@ -49,7 +49,7 @@ for v in variants:
 
 print(f"{'shape':10s} {'epi':>3s} " + " ".join(f"{'v' + str(v):>9s}" for v in variants) + "   (TFLOP/s)")
 tot = {v: 0.0 for v in variants}
-for name, M, N, K in SHAPES_NT:
+for name, M, N, K in (SHAPES_NT if variants else []):
     a = torch.randn(M, K, device=dev).bfloat16()
     b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
     bias = torch.randn(N, device=dev)
@@ -73,8 +73,8 @@ for name, M, N, K in SHAPES_NT:
 print("sum ms per variant:", {v: round(t, 2) for v, t in tot.items()})
 _lib.call("ocn_set_gemm_variant", 0)
 
-print("TN (wgrad): variant 1 = 128x128 two-stage, 2 = 256x256 ring")
-for tv in (1, 2):
+print("TN (wgrad): variant 1 = 128x128 two-stage, 2 = 256x256 ring, 3 = 256x256 hand-scheduled (tn5)")
+for tv in (1, 2, 3):
     _lib.call("ocn_set_gemm_variant", tv << 4)
     g = torch.Generator().manual_seed(1)
     M, N, K = 3000, 640, 328
@@ -90,10 +90,11 @@ for name, M, N, K in SHAPES_NT:
     dw = torch.zeros(N, K, device=dev)
     db = torch.zeros(N, device=dev)
     row = []
-    for tv in (1, 2):
+    for tv in (2, 3):
         _lib.call("ocn_set_gemm_variant", tv << 4)
         ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
-        row.append(f"v{tv}: {2.0 * M * N * K / ms / 1e9:6.0f} TF/s {ms:.3f} ms")
+        ms0 = timeit(lambda: ops.gemm_tn_accum(a, b, dw, None))
+        row.append(f"v{tv}: {2.0 * M * N * K / ms / 1e9:6.0f} TF/s {ms:.3f} ms (no dbias {2.0 * M * N * K / ms0 / 1e9:6.0f})")
     print(f"{name:10s} dW[{N},{K}] over M={M}:  " + "   ".join(row))
     del a, b
 _lib.call("ocn_set_gemm_variant", 0)
