@@ -62,6 +62,9 @@ int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW,
  *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
  *   bits 8..   developer ablation mask of the ring kernel (timing experiments only; results are wrong) */
 int ocn_set_gemm_variant(int nt_variant);
+/* developer knobs (process-global, timing experiments only; key 1 = attention-backward ablation mask:
+ *   1 skip the input staging, 2 skip the arithmetic, 4 skip the output stores -- results are wrong when non-zero) */
+int ocn_set_tuning(int key, int value);
 
 /* ---- casts -------------------------------------------------------------------------------------
  * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */

@@ -20,6 +20,10 @@ namespace {
 
 OCN_DEV int swz_nt(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
+}  // namespace
+extern int g_ocn_tuning[16];
+namespace {
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                         bf16* __restrict__ dqkv, int L, int H, int causal, float scale) {
+                                                         bf16* __restrict__ dqkv, int L, int H, int causal, float scale, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -193,12 +197,14 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
     char* sdO = smem + 3 * LP * 128;
     float* sLse = (float*)(smem + 4 * LP * 128);
     float* sDelta = sLse + LP;
+    if (!(ablate & 1)) {
     stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
     stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
     stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
     stage_head(dobase, (size_t)C, L, LP, sdO, wave, nwaves, lane);
+    }
     // delta[q] = sum_d dO[q,d] * O[q,d]; lse in exp2 units
-    for (int idx = threadIdx.x; idx < LP * 8; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < ((ablate & 1) ? 0 : LP * 8); idx += blockDim.x) {
         const int r = idx >> 3, c = idx & 7;
         const int gr = r < L ? r : L - 1;
         const bf16x8 a = *(const bf16x8*)(dobase + (size_t)gr * C + c * 8);
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
             qf[s] = frag_rows(sQ, query, s, lane);
             dof[s] = frag_rows(sdO, query, s, lane);
         }
-        const int nkb = causal ? qb + 1 : nwaves;
+        const int nkb = (ablate & 2) ? 0 : (causal ? qb + 1 : nwaves);
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
@@ -271,9 +277,9 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
         __syncthreads();
         bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
         stage_tile(sK, wave * 32, lane, dq0, dq1, 1.0f);
-        flush_tile(sK, wave * 32, lane, dbase, rs, L);
+        if (!(ablate & 4)) flush_tile(sK, wave * 32, lane, dbase, rs, L);
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-        const int qb0 = causal ? kb : 0;
+        const int qb0 = (ablate & 2) ? nwaves : (causal ? kb : 0);
         for (int qb = qb0; qb < nwaves; ++qb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
@@ -302,8 +308,10 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
         __syncthreads();
         stage_tile(sQ, wave * 32, lane, dk0, dk1, 1.0f);
         stage_tile(sdO, wave * 32, lane, dv0, dv1, 1.0f);
-        flush_tile(sQ, wave * 32, lane, dbase + C, rs, L);
-        flush_tile(sdO, wave * 32, lane, dbase + 2 * C, rs, L);
+        if (!(ablate & 4)) {
+            flush_tile(sQ, wave * 32, lane, dbase + C, rs, L);
+            flush_tile(sdO, wave * 32, lane, dbase + 2 * C, rs, L);
+        }
     }
 }
 
@@ -351,7 +359,7 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
             attr_set = true;
         }
         hipLaunchKernelGGL(attn_bwd_kernel<256>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale);
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -359,7 +367,7 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
             attr_set = true;
         }
         hipLaunchKernelGGL(attn_bwd_kernel<640>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale);
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
     }
     OCN_CHECK_LAUNCH("ocn_attn_bwd");
     return OCN_OK;

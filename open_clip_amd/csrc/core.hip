@@ -14,7 +14,15 @@ void ocn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ocn_last_error(void) { return g_err; }
-extern "C" int ocn_version(void) { return 100; }
+extern "C" int ocn_version(void) { return 101; }
+
+// developer tuning / ablation knobs (process-global; timing experiments only)
+int g_ocn_tuning[16] = {0};
+extern "C" int ocn_set_tuning(int key, int value) {
+    OCN_CHECK_ARG(key >= 0 && key < 16, "ocn_set_tuning: key %d out of range", key);
+    g_ocn_tuning[key] = value;
+    return OCN_OK;
+}
 
 namespace {
 // C[32,32] = A[32,16] . B[32,16]^T with ONE v_mfma_f32_32x32x16_bf16 -- pins operand/accumulator lane maps

@@ -12,6 +12,7 @@ struct GemmNtArgs {
     int lda, ldb, ldc, M, N, K;
     float alpha;
     int tiles_n, ntiles;
+    int band;    // tile walk order: column bands of `band` n-tiles, row-major inside a band (gemm_nt5.hip)
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
 };
 

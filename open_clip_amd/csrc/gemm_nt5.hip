@@ -119,7 +119,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         for (int g = 0; g < 4; ++g) {
                             f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
                             if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else v = v + bv[hb][g];
-                            if (EPI == OCN_EPI_BIAS_GELU && rnd == 1) v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                            if (EPI == OCN_EPI_BIAS_GELU && rnd == 1 && !(a.ablate & 1)) v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
                             const bf16x4 pk = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                             lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk);
                         }
@@ -178,8 +178,9 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                 if (EPI == OCN_EPI_BIAS_RESID_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, 0);
                 } else if (EPI == OCN_EPI_DGELU) {
-                    const bf16x4 o4 = {f2bf(v[0] * dgelu_f(ex[it][0])), f2bf(v[1] * dgelu_f(ex[it][1])),
-                                       f2bf(v[2] * dgelu_f(ex[it][2])), f2bf(v[3] * dgelu_f(ex[it][3]))};
+                    f32x4 dg = ex[it];
+                    if (!(a.ablate & 1)) dg = (f32x4){dgelu_f(dg[0]), dgelu_f(dg[1]), dgelu_f(dg[2]), dgelu_f(dg[3])};  // (developer knob: skip the VALU work)
+                    const bf16x4 o4 = {f2bf(v[0] * dg[0]), f2bf(v[1] * dg[1]), f2bf(v[2] * dg[2]), f2bf(v[3] * dg[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, 0);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, 0);
@@ -230,10 +231,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         voB[j] = (unsigned)(((u >> 5) * 64 + (u & 31)) * a.ldb * 2 + c * 16);
     }
     const unsigned a_half = (unsigned)(64 * a.lda * 2), b_half = (unsigned)(32 * a.ldb * 2);  // A1 - A0, B1 - B0 (bytes)
+    // Tile walk: the linear order is BAND-major -- column bands of a.band n-tiles, row-major inside a band -- and every
+    // XCD owns a contiguous piece of it (xcd_remap), so the 32 tiles an XCD works on at any time are 32/band rows x band
+    // columns and the band's B panels (band x 256 x K bf16) stay resident in that XCD's 4 MiB L2 while the A panels stream
+    // through once per band.  Row-major over all of N (band = tiles_n) re-reads the whole of B once per round of tiles when
+    // B does not fit in L2 next to the A panels: measured 1.74 GB of L2-miss reads per launch instead of 0.32 GB on the
+    // [204800 x 3072 x 768] GEMM (profiles/r01_pmc_hbm_traffic.txt).
+    const int tiles_m = a.ntiles / a.tiles_n;
+    const int band_tiles = tiles_m * a.band;
     auto tile_origin = [&](int i, int& m0, int& n0) {
         const int tile = xcd_remap((int)blockIdx.x + i * G, a.ntiles);
-        m0 = (tile / a.tiles_n) * 256;
-        n0 = (tile % a.tiles_n) * 256;
+        const int cb = tile / band_tiles, r = tile - cb * band_tiles;
+        const int width = min(a.band, a.tiles_n - cb * a.band);
+        const int mi = r / width;
+        m0 = mi * 256;
+        n0 = (cb * a.band + (r - mi * width)) * 256;
     };
     auto make_desc = [&](const bf16* base, int row0, int rows, int ld) -> u32x4 {
         long bytes = (long)(rows - row0) * ld * 2;
@@ -425,6 +437,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 
 int g_num_cu = 0;
 
+// Band width of the tile walk (see tile_origin).  L2-miss read model per launch, in bytes:
+//   row-major over all of N:  A once + B once per round of tiles per XCD when B does not stay in L2  = A + (ntiles / 32) * B
+//   nb bands:                 A once per band + B once per XCD                                        = nb * A + 8 * B
+// A band must leave room for the streaming A panels: band * panel <= 2.5 MiB of the XCD's 4 MiB.  `forced` = developer knob.
+int nt5_band(int M, int N, int K, int forced) {
+    const int tiles_n = ocn_cdiv(N, 256);
+    if (forced > 0) return forced < tiles_n ? forced : tiles_n;
+    const double panel = 256.0 * K * 2, Bt = (double)N * K * 2, At = (double)M * K * 2;
+    const double l2_band = 2.5 * 1048576;
+    if (Bt <= l2_band) return tiles_n;
+    const double ntiles = (double)ocn_cdiv(M, 256) * tiles_n;
+    const double row_major = At + (ntiles / 32.0 < 8.0 ? 8.0 : ntiles / 32.0) * Bt;
+    for (int nb = 2; nb <= tiles_n; ++nb) {
+        const int band = ocn_cdiv(tiles_n, nb);
+        if (band * panel > l2_band) continue;
+        return (nb * At + 8.0 * Bt < row_major) ? band : tiles_n;  // the first feasible nb is the cheapest banded walk
+    }
+    return tiles_n;
+}
+
 template <int EPI>
 int launch5(GemmNtArgs a, hipStream_t st) {
     if (g_num_cu == 0) {
@@ -435,6 +467,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     }
     a.tiles_n = ocn_cdiv(a.N, 256);
     a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
+    a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
     const int grid = a.ntiles < g_num_cu ? a.ntiles : g_num_cu;
     if (a.ablate & 64) {  // developer build: per-tile timeline into a side buffer passed in a.resid/a.aux (tools/gemm_trace.py)
         static bool dbg_attr_set = false;

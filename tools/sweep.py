@@ -1,0 +1,82 @@
+"""Developer sweeps on the MI355X (run through gpurun): tile-walk band width of the persistent NT GEMM, epilogue VALU
+cost, and attention-backward ablations (what the loads / the arithmetic / the stores cost on their own)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_clip_amd import _lib, ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+Mi, Mt = 4096 * 50, 4096 * 77
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return best
+
+
+def nt_sweep():
+    cases = [("img qkv", Mi, 2304, 768, [0], [9, 5, 3]), ("img fc", Mi, 3072, 768, [0, 1, 3], [12, 6, 4, 3, 2]),
+             ("img proj", Mi, 768, 3072, [0, 2], [3, 1]), ("img dh1", Mi, 768, 2304, [0], [3, 1]),
+             ("txt qkv", Mt, 1536, 512, [0], [6, 3]), ("txt fc", Mt, 2048, 512, [0, 1, 3], [8, 4, 2]),
+             ("glogits", 32768, 32768, 512, [4], [128, 10, 8, 4])]
+    for name, M, N, K, epis, bands in cases:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, device=dev)
+        for epi in epis:
+            f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
+            out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+            resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
+            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            row = []
+            for band in bands + [0]:
+                _lib.call("ocn_set_gemm_variant", 5 | (band << 16))
+                ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
+                row.append(f"band {band:3d}: {2.0 * M * N * K / ms / 1e9:6.0f} TF/s {ms:.3f} ms")
+            if epi in (1, 3):  # no-VALU epilogue at the automatic band
+                _lib.call("ocn_set_gemm_variant", 5 | (1 << 8))
+                ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
+                row.append(f"no-gelu-math: {2.0 * M * N * K / ms / 1e9:6.0f} TF/s")
+            print(f"{name:9s} epi {epi}: " + " | ".join(row), flush=True)
+            del out, resid, aux
+        del a, b
+    _lib.call("ocn_set_gemm_variant", 0)
+
+
+def attn_sweep():
+    for name, B, L, H, causal in [("img", 4096, 50, 12, False), ("txt", 4096, 77, 8, True)]:
+        C = H * 64
+        qkv = torch.randn(B * L, 3 * C, device=dev).bfloat16()
+        do = torch.randn(B * L, C, device=dev).bfloat16()
+        out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125)
+        ms_f = timeit(lambda: ops.attn_fwd(qkv, B, L, H, causal, 0.125))
+        gb_f = B * L * C * 2 * 4 / 1e9
+        row = [f"fwd {ms_f:.3f} ms ({gb_f / ms_f:.2f} TB/s)"]
+        gb_b = B * L * C * 2 * 8 / 1e9
+        for mask in (0, 1, 2, 4, 3, 5, 6, 7):
+            _lib.call("ocn_set_tuning", 1, mask)
+            ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
+            row.append(f"bwd[-{'L' if mask & 1 else ''}{'C' if mask & 2 else ''}{'S' if mask & 4 else ''}] {ms:.3f} ms")
+        _lib.call("ocn_set_tuning", 1, 0)
+        print(f"attn {name} L={L}: " + " | ".join(row) + f"   (bwd algorithmic {gb_b:.2f} GB)", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "attn"):
+        attn_sweep()
+    if what in ("all", "nt"):
+        nt_sweep()
