@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="developer: value for ocn_set_gemm_variant (kernel choice / ablation knobs)")
+    ap.add_argument("--dist-backend", default="nccl", help="developer: 'gloo' + OCN_BENCH_ONE_DEVICE=1 runs N ranks on one GPU")
     return ap.parse_args()
 
 
@@ -116,19 +118,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if os.environ.get("OCN_BENCH_ONE_DEVICE") == "1":  # developer mode: every rank on GPU 0 (needs --dist-backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.loss import NativeClipLoss
     from open_clip_amd.model import NativeCLIP
-    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
     from open_clip_amd.synth import init_state_dict, synthetic_batch
 
+    if args.gemm_variant:
+        from open_clip_amd import _lib
+        _lib.call("ocn_set_gemm_variant", args.gemm_variant)
     cfg = get_model_config(args.model)
     torch.manual_seed(0)
     model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True)
@@ -139,7 +149,7 @@ def main():
     B = args.local_batch
     batch = synthetic_batch(cfg, B, seed=1234, rank=rank, device=dev)
     loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world)
-    opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4, betas=(0.9, 0.98), eps=1e-6)
+    opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=128, gradient_as_bucket_view=True)
@@ -177,7 +187,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -101,6 +101,11 @@ int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float
  * embed_assemble_bwd: dpatch bf16 [B*G, C] = demb[b,1+g,:]; dpos[T,C] += sum_b demb; dcls[C] += sum_b demb[b,0] */
 int ocn_patchify(const void* image, int image_is_bf16, void* patches, int B, int H, int W, int P, int Kpad,
                  ocn_stream_t stream);
+/* uint8 input path (8f-4): pixels as decoded ([B,H,W,3] when hwc, else [B,3,H,W]); the kernel applies ToTensor + Normalize
+ * ((x/255 - mean[c]) / std[c]; mean3 / std3 = HOST pointers to 3 floats, src/open_clip/constants.py:1-2) while building the
+ * same bf16 patch matrix as ocn_patchify. */
+int ocn_patchify_u8(const void* image_u8, int hwc, const float* mean3, const float* std3, void* patches, int B, int H, int W,
+                    int P, int Kpad, ocn_stream_t stream);
 int ocn_embed_assemble_fwd(const float* patch_out, const float* cls, const float* pos, float* emb, int B, int G, int C,
                            ocn_stream_t stream);
 int ocn_embed_assemble_bwd(const float* demb, void* dpatch_bf16, float* dpos, float* dcls, int B, int G, int C,
@@ -149,6 +154,18 @@ int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N,
 int ocn_sumsq_accum(const float* x, int64_t n, float* out, ocn_stream_t stream);
 int ocn_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const float* clip_coef, ocn_stream_t stream);
+
+/* Whole-model optimizer step in one launch (8f-1): `entries` = device array of 88-byte records
+ *   { float* w; const float* g; float* m; float* v; bf16* w16n; bf16* w16t; int64 numel; int32 rows, cols, mode, pad;
+ *     float lr, wd, bc1 (= 1 - beta1^step), bc2_sqrt (= sqrt(1 - beta2^step)); }
+ * `chunks` = device array of int32 pairs {entry, index}: 8192-element ranges (mode 0 = 16-byte vectors, 2 = scalar) or 64x64
+ * tiles of a [rows, cols] weight (mode 1; rows, cols % 64 == 0).  AdamW as ocn_adamw_step; additionally rewrites the bf16
+ * operand copies w16n [rows, cols] and (mode 1) w16t [cols, rows] when non-NULL.  gnorm_sq != NULL: gradients are scaled by
+ * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)) = torch.nn.utils.clip_grad_norm_ (train.py:181); ocn_sumsq_multi accumulates
+ * the squared norm of every entry's gradient into out[0]. */
+int ocn_adamw_multi(const void* entries, const void* chunks, int n_chunks, float beta1, float beta2, float eps,
+                    const float* gnorm_sq, float max_norm, ocn_stream_t stream);
+int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, ocn_stream_t stream);
 
 /* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
 int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,

@@ -26,6 +26,7 @@ SIGNATURES = {
     "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "ocn_patchify_u8": [_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _p, _i, _i, _i, _i, _i, _p],
     "ocn_embed_assemble_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_embed_assemble_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_token_embed_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -39,6 +40,8 @@ SIGNATURES = {
     "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p],
     "ocn_sumsq_accum": [_p, _l, _p, _p],
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
+    "ocn_adamw_multi": [_p, _p, _i, _f, _f, _f, _p, _f, _p],
+    "ocn_sumsq_multi": [_p, _p, _i, _p, _p],
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }

@@ -27,6 +27,42 @@ __global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ ou
     }
 }
 
+// uint8 pixels (the decoded, resized image before ToTensor / Normalize, transform.py:367-510): the kernel applies
+// x/255, - mean[c], / std[c] (constants.py:1-2) while it builds the bf16 patch matrix -- 4x fewer bytes over PCIe and HBM
+// than the fp32 tensor prepare_batch moves (base_task.py:135-157).  hwc = 1: [B,H,W,3] (PIL / decoder order), 0: [B,3,H,W].
+struct NormC {
+    float scale[3], shift[3];  // y = x * scale[c] + shift[c]
+};
+__global__ void patchify_u8_kernel(const unsigned char* __restrict__ img, bf16* __restrict__ out, int B, int H, int W, int P, int Kpad,
+                                   long total, int hwc, NormC nc) {
+    const int gh = H / P, gw = W / P, KP = 3 * P * P, kv = Kpad / 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / kv;
+        const int k = (int)(idx % kv) * 2;
+        bf16* o = out + row * Kpad + k;
+        if (k >= KP) {
+            o[0] = (bf16)0.f;
+            o[1] = (bf16)0.f;
+            continue;
+        }
+        const int c = k / (P * P), rem = k % (P * P), i = rem / P, j = rem % P;
+        const int b = (int)(row / (gh * gw)), g = (int)(row % (gh * gw)), py = g / gw, px = g % gw;
+        const int y = py * P + i, x = px * P + j;
+        float v0, v1;
+        if (hwc) {
+            const unsigned char* s = img + (((size_t)b * H + y) * W + x) * 3 + c;
+            v0 = (float)s[0];
+            v1 = (float)s[3];
+        } else {
+            const unsigned char* s = img + (((size_t)b * 3 + c) * H + y) * W + x;
+            v0 = (float)s[0];
+            v1 = (float)s[1];
+        }
+        o[0] = f2bf(fmaf(v0, nc.scale[c], nc.shift[c]));
+        o[1] = f2bf(fmaf(v1, nc.scale[c], nc.shift[c]));
+    }
+}
+
 // ---- class token + positional embedding (transformer.py:799-801) --------------------------------
 __global__ void embed_assemble_fwd_kernel(const float* __restrict__ po, const float* __restrict__ cls,
                                           const float* __restrict__ pos, float* __restrict__ emb, int B, int G, int C) {
@@ -225,6 +261,24 @@ extern "C" int ocn_patchify(const void* image, int image_is_bf16, void* patches,
         else hipLaunchKernelGGL((patchify_kernel<float, 2>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const float*)image, (bf16*)patches, B, H, W, P, Kpad, total);
     }
     OCN_CHECK_LAUNCH("ocn_patchify");
+    return OCN_OK;
+}
+
+extern "C" int ocn_patchify_u8(const void* image_u8, int hwc, const float* mean3, const float* std3, void* patches, int B, int H, int W,
+                               int P, int Kpad, ocn_stream_t stream) {
+    OCN_CHECK_ARG(image_u8 && patches && mean3 && std3, "ocn_patchify_u8: null operand");
+    OCN_CHECK_ARG(B > 0 && P > 0 && H % P == 0 && W % P == 0 && P % 2 == 0, "ocn_patchify_u8: bad geometry H=%d W=%d P=%d", H, W, P);
+    OCN_CHECK_ARG(Kpad >= 3 * P * P && Kpad % 4 == 0, "ocn_patchify_u8: Kpad=%d too small / not a multiple of 4", Kpad);
+    NormC nc;
+    for (int c = 0; c < 3; ++c) {  // mean3 / std3 are HOST pointers (three floats each)
+        OCN_CHECK_ARG(std3[c] > 0.f, "ocn_patchify_u8: std must be positive");
+        nc.scale[c] = 1.0f / (255.0f * std3[c]);
+        nc.shift[c] = -mean3[c] / std3[c];
+    }
+    const long total = (long)B * (H / P) * (W / P) * (Kpad / 2);
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)image_u8,
+                       (bf16*)patches, B, H, W, P, Kpad, total, hwc, nc);
+    OCN_CHECK_LAUNCH("ocn_patchify_u8");
     return OCN_OK;
 }
 

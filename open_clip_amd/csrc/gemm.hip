@@ -748,7 +748,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (bf16*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.ablate = 0;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.ablate = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OCN_EPI_BF16: return launch_nt<OCN_EPI_BF16>(a, st);
@@ -777,7 +777,7 @@ extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb,
     OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "ocn_gemm_tn_accum: operands must be 16-byte aligned");
     GemmTnArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.dW = dW; a.dbias = dbias;
-    a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
+    a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.ablate = 0;
     const bool big = (long)M * N * K >= (1L << 31) && N >= 256 && K >= 256;
     if (g_tn_variant == 3 || (g_tn_variant == 0 && big)) {  // hand-scheduled 256x256 kernel (gemm_tn5.hip); falls through if the shape does not fit it
         const int rc = ocn_launch_tn5(a, (hipStream_t)stream);

@@ -12,6 +12,7 @@ struct GemmNtArgs {
     int lda, ldb, ldc, M, N, K;
     float alpha;
     int tiles_n, ntiles;
+    int stagger; // start offset between the 4 phase classes of workgroups, in 100 MHz ticks (0 = none; gemm_nt5.hip)
     int band;    // tile walk order: column bands of `band` n-tiles, row-major inside a band (gemm_nt5.hip)
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
 };
@@ -32,6 +33,7 @@ struct GemmTnArgs {
     int lda, ldb, ldw, M, N, K;
     float alpha;
     int tiles_n, tiles_k, chunk, nwg;
+    int ablate;  // developer knob (ocn_set_tuning key 4): 1 = skip the atomic epilogue (timing only)
 };
 
 // hand-scheduled 256x256 TN (wgrad) kernel (gemm_tn5.hip); returns 1 if the shape is not supported by it (caller falls back)

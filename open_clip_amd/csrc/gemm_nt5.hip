@@ -68,7 +68,8 @@ OCN_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long row0, int rows_t
 }
 
 template <int EPI>
-OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg) {
+OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg,
+                       long long* dbg = nullptr) {
     // Lane constants are laundered through an empty asm once per tile: otherwise hipcc hoists ~40 VGPRs of epilogue
     // addresses (per-row store offsets, swizzled staging addresses) out of the tile loop and keeps them live across the
     // main loop, which is already at the 256-register budget.
@@ -102,6 +103,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     // stores below drain under them.  (hipcc does not know about the asm LDS-DMAs; its own loads / stores below get
     // ordinary counted waits.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dbg) dbg[5] = wall_clock64();
     const int row_w = wm * 128;  // this wave's first row inside the tile
     if (BF16_STAGED) {
         constexpr int ROUNDS = (EPI == OCN_EPI_BIAS_GELU) ? 2 : 1;
@@ -113,6 +115,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+                    if (dbg && ha == 1 && s == 0 && rnd == 0) dbg[6] = wall_clock64();
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -163,6 +166,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 #pragma unroll
         for (int blk = 0; blk < 8; ++blk) {
             const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
+            if (dbg && blk == 4) dbg[6] = wall_clock64();
             f32x4 (&ex)[4] = (blk & 1) ? exB : exA;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -302,6 +306,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 #define DMA_B0(J, P) DMA(dB, voB, ab_k, B_SLOT(0, P), J)
 #define DMA_B1(J, P) DMA(dB, voB, ab_k + b_half, B_SLOT(1, P), J)
 
+    // ---- phase stagger -------------------------------------------------------------------------------------------
+    // Persistent workgroups launched together walk tiles of equal cost in lockstep: every CU is in its main loop (HBM
+    // idle) and then every CU is in its epilogue at once -- a chip-wide burst of 256 x 128..256 KiB of stores (+ residual /
+    // pre-activation reads) that exceeds what the L2s can buffer, so the epilogue runs at HBM write speed while the MFMA
+    // pipes idle (measured with the DBG timeline: 11 us per tile for the two-output GELU epilogue against 3 us for one
+    // bf16 output; profiles/r01_nt5_tile_timeline.txt).  Workgroups therefore start in 4 phase classes (inside every XCD),
+    // a quarter of a tile time apart, which spreads the epilogue traffic over the whole tile period.
+    if (a.stagger > 0) {
+        const int phase = ((int)blockIdx.x >> 3) & 3;
+        if (phase) {
+            const long long until = wall_clock64() + (long long)phase * a.stagger;
+            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+
     // ---- prologue: K-tiles 0 and 1 (minus A1(1)) ----
     set_ab(0);
     set_a1(0);
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         STAMP(3)
         int m0, n0;
         tile_origin(i, m0, n0);
-        epilogue5<EPI>(a, acc, m0, n0, wm, wn, lane, stg);
+        epilogue5<EPI>(a, acc, m0, n0, wm, wn, lane, stg, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
         STAMP(4)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released
@@ -457,6 +476,19 @@ int nt5_band(int M, int N, int K, int forced) {
     return tiles_n;
 }
 
+// Phase offset between workgroup classes (100 MHz ticks): a quarter of the expected tile time (main loop ~2 us per 64-wide
+// K-tile + epilogue), only for epilogues whose burst does not fit the L2s and only when a workgroup walks enough tiles to
+// repay the one-off delay.  `forced` (developer knob, us per phase): 0 = automatic, 63 = off.
+template <int EPI>
+int nt5_stagger(int ntiles, int K, int forced) {
+    if (forced == 63) return 0;
+    if (forced > 0) return forced * 100;
+    constexpr bool heavy = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
+    if (!heavy || ntiles < 12 * g_num_cu) return 0;
+    const int tile_us = (K / 64) * 2 + 6;
+    return tile_us * 100 / 4;
+}
+
 template <int EPI>
 int launch5(GemmNtArgs a, hipStream_t st) {
     if (g_num_cu == 0) {
@@ -468,6 +500,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.tiles_n = ocn_cdiv(a.N, 256);
     a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
     a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
+    a.stagger = nt5_stagger<EPI>(a.ntiles, a.K, (a.ablate >> 13) & 63);
     const int grid = a.ntiles < g_num_cu ? a.ntiles : g_num_cu;
     if (a.ablate & 64) {  // developer build: per-tile timeline into a side buffer passed in a.resid/a.aux (tools/gemm_trace.py)
         static bool dbg_attr_set = false;

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
 
     // ---- epilogue: fp32 atomics (lanes of a half-wave hit 32 consecutive k = one 128-byte line) ---------------------------
     const int lr = lane & 31;
+    if (a.ablate & 1) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int blk = (i + wk) & 3;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
 int g_tn5_num_cu = 0;
 
 }  // namespace
+extern int g_ocn_tuning[16];
 
 int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     if (a.N % 8 || a.K % 8 || a.lda % 8 || a.ldb % 8) return 1;
@@ -265,6 +267,7 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         g_tn5_num_cu = n;
     }
+    a.ablate = g_ocn_tuning[4];
     a.tiles_n = ocn_cdiv(a.N, 256);
     a.tiles_k = ocn_cdiv(a.K, 256);
     const int ntile = a.tiles_n * a.tiles_k;

@@ -68,6 +68,142 @@ __global__ void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
     }
 }
 
+
+// ---- whole-model optimizer step in ONE launch --------------------------------------------------------
+// The host describes every tensor by an AdamEntry and cuts the work into chunks {entry, index}: a chunk is 8192 consecutive
+// elements (mode 0: 16-byte vector path, mode 2: scalar path for odd sizes / alignments) or one 64x64 tile of a 2-D GEMM
+// weight (mode 1).  Besides torch.optim.AdamW's update the kernel refreshes the bf16 operand copies of the GEMM weights in
+// the same pass -- the plain copy [rows, cols] and, in tile mode, the transposed copy [cols, rows] through LDS -- and applies
+// the clip_grad_norm_ coefficient computed from the squared gradient norm that ocn_sumsq_multi left on the device.
+struct AdamEntry {
+    float* w;
+    const float* g;
+    float* m;
+    float* v;
+    bf16* w16n;
+    bf16* w16t;
+    long numel;
+    int rows, cols, mode, pad;
+    float lr, wd, bc1, bc2_sqrt;
+};
+static_assert(sizeof(AdamEntry) == 88, "AdamEntry layout is mirrored by open_clip_amd/optim.py");
+constexpr int ADAM_CHUNK = 8192;
+
+OCN_DEV float adam_one(float w, float gi, float& m, float& v, float lr, float wd, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+    float p = w * (1.0f - lr * wd);
+    m = m + (gi - m) * (1.0f - b1);
+    v = v * b2 + gi * gi * (1.0f - b2);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    return p - (lr / bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamEntry* __restrict__ entries, const int2* __restrict__ chunks,
+                                                          float b1, float b2, float eps, const float* __restrict__ gnorm_sq, float max_norm) {
+    __shared__ float tile[64][65];
+    const int2 ch = chunks[blockIdx.x];
+    const AdamEntry e = entries[ch.x];
+    float gs = 1.0f;
+    if (gnorm_sq) gs = fminf(1.0f, max_norm / (sqrtf(*gnorm_sq) + 1e-6f));  // torch.nn.utils.clip_grad_norm_
+    if (e.mode == 1) {
+        const int tiles_c = e.cols >> 6;
+        const int r0 = (ch.y / tiles_c) * 64, c0 = (ch.y % tiles_c) * 64;
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+        const bool g_vec = ((uintptr_t)e.g & 15) == 0;  // gradients may be views into a DDP bucket at any 4-byte offset
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = ty + 16 * k;
+            const size_t o = (size_t)(r0 + r) * e.cols + c0 + tx * 4;
+            const f32x4 g4 = g_vec ? *(const f32x4*)(e.g + o) : (f32x4){e.g[o], e.g[o + 1], e.g[o + 2], e.g[o + 3]};
+            const f32x4 w4 = *(const f32x4*)(e.w + o);
+            f32x4 m4 = *(const f32x4*)(e.m + o), v4 = *(const f32x4*)(e.v + o), p4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float mj = m4[j], vj = v4[j];
+                p4[j] = adam_one(w4[j], g4[j] * gs, mj, vj, e.lr, e.wd, b1, b2, eps, e.bc1, e.bc2_sqrt);
+                m4[j] = mj;
+                v4[j] = vj;
+            }
+            *(f32x4*)(e.w + o) = p4;
+            *(f32x4*)(e.m + o) = m4;
+            *(f32x4*)(e.v + o) = v4;
+            if (e.w16n) *(bf16x4*)(e.w16n + o) = (bf16x4){f2bf(p4[0]), f2bf(p4[1]), f2bf(p4[2]), f2bf(p4[3])};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[r][tx * 4 + j] = p4[j];
+        }
+        if (e.w16t) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = ty + 16 * k;  // row of the transposed copy
+                const bf16x4 o4 = {f2bf(tile[tx * 4][c]), f2bf(tile[tx * 4 + 1][c]), f2bf(tile[tx * 4 + 2][c]), f2bf(tile[tx * 4 + 3][c])};
+                *(bf16x4*)(e.w16t + (size_t)(c0 + c) * e.rows + r0 + tx * 4) = o4;
+            }
+        }
+        return;
+    }
+    const long base = (long)ch.y * ADAM_CHUNK;
+    const long end = base + ADAM_CHUNK < e.numel ? base + ADAM_CHUNK : e.numel;
+    if (e.mode == 0) {
+        for (long i = base + threadIdx.x * 4; i + 3 < end; i += 1024) {
+            const f32x4 g4 = *(const f32x4*)(e.g + i), w4 = *(const f32x4*)(e.w + i);
+            f32x4 m4 = *(const f32x4*)(e.m + i), v4 = *(const f32x4*)(e.v + i), p4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float mj = m4[j], vj = v4[j];
+                p4[j] = adam_one(w4[j], g4[j] * gs, mj, vj, e.lr, e.wd, b1, b2, eps, e.bc1, e.bc2_sqrt);
+                m4[j] = mj;
+                v4[j] = vj;
+            }
+            *(f32x4*)(e.w + i) = p4;
+            *(f32x4*)(e.m + i) = m4;
+            *(f32x4*)(e.v + i) = v4;
+            if (e.w16n) *(bf16x4*)(e.w16n + i) = (bf16x4){f2bf(p4[0]), f2bf(p4[1]), f2bf(p4[2]), f2bf(p4[3])};
+        }
+        const long tail = end - ((end - base) & 3);  // numel % 4 leftovers of the last chunk
+        if (tail + threadIdx.x < end) {
+            const long i = tail + threadIdx.x;
+            float mi = e.m[i], vi = e.v[i];
+            const float p = adam_one(e.w[i], e.g[i] * gs, mi, vi, e.lr, e.wd, b1, b2, eps, e.bc1, e.bc2_sqrt);
+            e.w[i] = p; e.m[i] = mi; e.v[i] = vi;
+            if (e.w16n) e.w16n[i] = f2bf(p);
+        }
+    } else {
+        for (long i = base + threadIdx.x; i < end; i += 256) {
+            float mi = e.m[i], vi = e.v[i];
+            const float p = adam_one(e.w[i], e.g[i] * gs, mi, vi, e.lr, e.wd, b1, b2, eps, e.bc1, e.bc2_sqrt);
+            e.w[i] = p; e.m[i] = mi; e.v[i] = vi;
+            if (e.w16n) e.w16n[i] = f2bf(p);
+        }
+    }
+}
+
+// out[0] += sum over every tensor of g^2 (same entry / chunk tables as adamw_multi_kernel)
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const AdamEntry* __restrict__ entries, const int2* __restrict__ chunks,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4];
+    const int2 ch = chunks[blockIdx.x];
+    const AdamEntry e = entries[ch.x];
+    float s = 0.f;
+    if (e.mode == 1) {
+        const int tiles_c = e.cols >> 6;
+        const int r0 = (ch.y / tiles_c) * 64, c0 = (ch.y % tiles_c) * 64;
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* gp = e.g + (size_t)(r0 + ty + 16 * k) * e.cols + c0 + tx * 4;
+            s += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2] + gp[3] * gp[3];
+        }
+    } else {
+        const long base = (long)ch.y * ADAM_CHUNK;
+        const long end = base + ADAM_CHUNK < e.numel ? base + ADAM_CHUNK : e.numel;
+        for (long i = base + threadIdx.x; i < end; i += 256) s += e.g[i] * e.g[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 int grid_for(long items, int block) {
     long g = (items + block - 1) / block;
     return (int)(g < 4096 ? (g > 0 ? g : 1) : 4096);
@@ -109,5 +245,22 @@ extern "C" int ocn_adamw_step(float* w, const float* g, float* m, float* v, void
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (bf16*)w_bf16, (long)n,
                        lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, clip_coef);
     OCN_CHECK_LAUNCH("ocn_adamw_step");
+    return OCN_OK;
+}
+
+extern "C" int ocn_adamw_multi(const void* entries, const void* chunks, int n_chunks, float beta1, float beta2, float eps,
+                               const float* gnorm_sq, float max_norm, ocn_stream_t stream) {
+    OCN_CHECK_ARG(entries && chunks && n_chunks > 0, "ocn_adamw_multi: bad arguments");
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)entries,
+                       (const int2*)chunks, beta1, beta2, eps, gnorm_sq, max_norm);
+    OCN_CHECK_LAUNCH("ocn_adamw_multi");
+    return OCN_OK;
+}
+
+extern "C" int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, ocn_stream_t stream) {
+    OCN_CHECK_ARG(entries && chunks && out && n_chunks > 0, "ocn_sumsq_multi: bad arguments");
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)entries,
+                       (const int2*)chunks, out);
+    OCN_CHECK_LAUNCH("ocn_sumsq_multi");
     return OCN_OK;
 }

@@ -99,7 +99,7 @@ class _PairTerm:
 
 class _ClipLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size):
+    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         s = float(logit_scale.detach())
         dev = I.device
@@ -129,6 +129,26 @@ class _ClipLossFn(torch.autograd.Function):
             d_all = None
             if gather_with_grad:                  # ... and through the gathered ones (summed over ranks in backward)
                 d_all = torch.cat([tt.dY(), ti.dY()], dim=1).contiguous()  # [N, 2E]: d I_all | d T_all
+        elif row_sharded and not gather_with_grad:
+            # Same loss and the same local gradients as the branch below (loss.py:106-107, :47-50), without its W-fold
+            # redundancy: rank r evaluates only ITS rows of logits_per_image and logits_per_text
+            # ([B, N] each, labels arange(B) + B*rank) with the global 1/(2N) weight, the row partial sums of the loss and of
+            # d/d logit_scale are all-reduced, and the gradient that reaches this rank's features through the COLUMNS of the
+            # other ranks' rows arrives by one reduce-scatter of [N, 2E] -- done here, since the loss computes its gradients
+            # in the forward.  6 GEMMs of 2*B*N*E flops instead of 6 of 2*N*N*E.
+            N = world_size * B
+            ti = PairTerm(I, T_all, s).compute_logits()
+            tt = PairTerm(T, I_all, s).compute_logits()
+            for term in (ti, tt):
+                term.softmax_ce(B * rank, 0.5 / N, 0.5 / N, acc)
+            dI, dT = ti.dX(), tt.dX()
+            through_cols = torch.cat([tt.dY(), ti.dY()], dim=1).contiguous()  # [N, 2E]: d I_all | d T_all from my rows
+            mine = torch.empty(B, 2 * E, dtype=F32, device=dev)
+            _reduce_scatter_sum(mine, through_cols)
+            dI = dI + mine[:, :E]
+            dT = dT + mine[:, E:]
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            d_all = None
         else:
             # loss.py:106-107: li = s I_all T_all^T, lt = li^T ; labels arange(N)
             N = world_size * B
@@ -159,7 +179,7 @@ class _ClipLossFn(torch.autograd.Function):
             _reduce_scatter_sum(mine, d_all)
             dI = dI + mine[:, :E]
             dT = dT + mine[:, E:]
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None
 
 
 PairTerm = _PairTerm  # the one seam tests replace to exercise the collective plumbing on CPU/gloo
@@ -169,16 +189,19 @@ class NativeClipLoss(nn.Module):
     """``open_clip.loss.ClipLoss`` (loss.py:57-141) on the HIP path.  ``cache_labels`` is accepted for
     signature parity; labels are an arange predicate inside the kernel (nothing to cache)."""
 
-    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1):
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, row_sharded=False):
         super().__init__()
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size = rank, world_size
+        # native extension (not a reference argument): evaluate the global loss (local_loss=False, gather_with_grad=False)
+        # by rows per rank -- identical value and gradients, 1/W of the logits work, one extra reduce-scatter
+        self.row_sharded = row_sharded
 
     def forward(self, image_features, text_features, logit_scale, logit_bias=None, output_dict=False):
         if logit_bias is not None:
             raise NotImplementedError("NativeClipLoss: a logit_bias shifts every logit of a softmax row equally; use NativeSigLipLoss")
         loss = _ClipLossFn.apply(image_features, text_features, logit_scale, self.local_loss, self.gather_with_grad,
-                                 self.rank, self.world_size)
+                                 self.rank, self.world_size, self.row_sharded)
         return {"contrastive_loss": loss} if output_dict else loss
 
 

@@ -47,6 +47,18 @@ class _WeightCache:
         self._d[key] = (ver, p.shape, out)
         return out
 
+    def peek(self, p, kind):
+        """the cached copy of ``p`` (possibly stale) or None -- NativeAdamW rewrites these in its own launch"""
+        hit = self._d.get((p.data_ptr(), kind))
+        return hit[2] if hit is not None and hit[1] == p.shape else None
+
+    def mark_fresh(self, p, n16, t16):
+        """the optimizer has just rewritten these copies from the updated parameter: record its new version"""
+        for kind, t in (("n", n16), ("t", t16)):
+            hit = self._d.get((p.data_ptr(), kind))
+            if t is not None and hit is not None and hit[2] is t:
+                self._d[(p.data_ptr(), kind)] = (p._version, p.shape, t)
+
     def clear(self):
         self._d.clear()
 
@@ -148,13 +160,19 @@ class _BlockFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 class _VisionEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, conv_w, cls, pos, lnw, lnb, cache, patch):
-        B, _, H, W = image.shape
+    def forward(ctx, image, conv_w, cls, pos, lnw, lnb, cache, patch, norm=None):
         width = conv_w.shape[0]
         KP = 3 * patch * patch
         Kpad = _round_up(KP, 64)
+        if image.dtype == torch.uint8:  # decoded pixels: ToTensor + Normalize happen inside the patch kernel (8f-4)
+            mean, std, hwc = norm
+            B = image.shape[0]
+            H, W = (image.shape[1], image.shape[2]) if hwc else (image.shape[2], image.shape[3])
+            patches = ops.patchify_u8(image.contiguous(), patch, Kpad, mean, std, hwc)
+        else:
+            B, _, H, W = image.shape
+            patches = ops.patchify(image.contiguous(), patch, Kpad)
         G = (H // patch) * (W // patch)
-        patches = ops.patchify(image.contiguous(), patch, Kpad)
         if Kpad == KP:
             w16 = cache.get(conv_w, "n")
         else:  # zero-padded K (patch 14: 588 -> 640); rare path, weight-sized
@@ -179,7 +197,7 @@ class _VisionEmbedFn(torch.autograd.Function):
         dw = torch.zeros(width, Kpad, dtype=F32, device=dev)
         ops.gemm_tn_accum(dpatch, patches, dw)
         dconv = (dw if Kpad == KP else dw[:, :KP].contiguous()).view(conv_w.shape)
-        return None, dconv, dcls, dpos, dlnw, dlnb, None, None
+        return None, dconv, dcls, dpos, dlnw, dlnb, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -354,6 +372,8 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self._cache = _WeightCache()
+        self.image_mean = (0.48145466, 0.4578275, 0.40821073)  # OPENAI_DATASET_MEAN / _STD (constants.py:1-2); used by the
+        self.image_std = (0.26862954, 0.26130258, 0.27577711)  # uint8 input path only (set_model_preprocess_cfg equivalent)
 
     def set_grad_checkpointing(self, enable=True, impl="inline"):
         self.transformer.set_grad_checkpointing(enable, impl)
@@ -367,12 +387,22 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
             p.requires_grad = False
 
     def forward(self, image, normalize=False):
+        """``image``: float [B,3,H,W] (already normalised, as the reference's transform produces) or uint8 pixels
+        ([B,3,H,W], or [B,H,W,3] as decoders emit them) which are normalised with ``image_mean`` / ``image_std`` in the
+        patch kernel."""
         B = image.shape[0]
-        if image.shape[2] != self.image_size[0] or image.shape[3] != self.image_size[1]:
-            raise RuntimeError(f"image size {tuple(image.shape[2:])} != {self.image_size}")
+        norm = None
+        if image.dtype == torch.uint8:
+            hwc = image.shape[-1] == 3 and image.shape[1] != 3
+            hw = tuple(image.shape[1:3]) if hwc else tuple(image.shape[2:])
+            norm = (self.image_mean, self.image_std, hwc)
+        else:
+            hw = tuple(image.shape[2:])
+        if hw != tuple(self.image_size):
+            raise RuntimeError(f"image size {hw} != {self.image_size}")
         T = self.grid_size[0] * self.grid_size[1] + 1
         x = _VisionEmbedFn.apply(image, self.conv1.weight, self.class_embedding, self.positional_embedding,
-                                 self.ln_pre.weight, self.ln_pre.bias, self._cache, self.patch_size[0])
+                                 self.ln_pre.weight, self.ln_pre.bias, self._cache, self.patch_size[0], norm)
         x = self.transformer(x, self._cache, B, T, False)
         return _HeadFn.apply(x, self.ln_post.weight, self.ln_post.bias, self.proj, None, self._cache, B, T, normalize)
 

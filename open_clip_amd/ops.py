@@ -141,6 +141,21 @@ def patchify(image, P, Kpad):
     return out
 
 
+def patchify_u8(image, P, Kpad, mean, std, hwc):
+    """uint8 pixels -> normalised bf16 patch matrix (ToTensor + Normalize fused; see ocn_patchify_u8)"""
+    import ctypes
+    if image.dtype != torch.uint8 or image.dim() != 4:
+        raise RuntimeError("patchify_u8: expected a 4-D uint8 image batch")
+    B = image.shape[0]
+    H, W = (image.shape[1], image.shape[2]) if hwc else (image.shape[2], image.shape[3])
+    if (image.shape[3] if hwc else image.shape[1]) != 3:
+        raise RuntimeError("patchify_u8: images must have 3 channels")
+    out = empty((B * (H // P) * (W // P), Kpad), BF16, image)
+    m3, s3 = (ctypes.c_float * 3)(*[float(v) for v in mean]), (ctypes.c_float * 3)(*[float(v) for v in std])
+    _lib.call("ocn_patchify_u8", _chk(image, torch.uint8, "image"), int(hwc), m3, s3, _chk(out, BF16, "patches"), B, H, W, P, Kpad, _stream())
+    return out
+
+
 def embed_assemble_fwd(patch_out, cls, pos, B, G, C):
     emb = empty((B * (G + 1), C), F32, patch_out)
     _lib.call("ocn_embed_assemble_fwd", _chk(patch_out, F32, "patch_out"), _chk(cls, F32, "cls"), _chk(pos, F32, "pos"),

@@ -65,7 +65,8 @@ def _worker(rank, world, port, q):
     for mode, kw in (("global", dict(local_loss=False, gather_with_grad=False)),
                      ("local_gwg", dict(local_loss=True, gather_with_grad=True)),
                      ("local_nograd", dict(local_loss=True, gather_with_grad=False)),
-                     ("global_gwg", dict(local_loss=False, gather_with_grad=True))):
+                     ("global_gwg", dict(local_loss=False, gather_with_grad=True)),
+                     ("global_rowsharded", dict(local_loss=False, gather_with_grad=False, row_sharded=True))):
         img = feats[rank, 0].clone().requires_grad_(True)
         txt = feats[rank, 1].clone().requires_grad_(True)
         s = torch.tensor(float(g["scale"]), requires_grad=True)
@@ -103,6 +104,13 @@ def test_native_losses_reproduce_reference_collective_semantics(world, port):
             np.testing.assert_allclose(di, g[pre + "dimg"], atol=2e-6, err_msg=pre)
             np.testing.assert_allclose(dt, g[pre + "dtxt"], atol=2e-6, err_msg=pre)
             assert abs(ds - float(g[pre + "dscale"])) < 1e-5
+        # the row-sharded evaluation of the global loss must give the reference's "global" numbers (value and local grads)
+        loss, di, dt, ds = got[rank]["global_rowsharded"]
+        pre = f"r{rank}/clip/global/"
+        assert abs(loss - float(g[pre + "loss"])) < 1e-5, rank
+        np.testing.assert_allclose(di, g[pre + "dimg"], atol=2e-6, err_msg="rowsharded " + pre)
+        np.testing.assert_allclose(dt, g[pre + "dtxt"], atol=2e-6, err_msg="rowsharded " + pre)
+        assert abs(ds - float(g[pre + "dscale"])) < 1e-5
         loss, di, dt, ds, db = got[rank]["siglip"]
         pre = f"r{rank}/siglip/bidir/"
         assert abs(loss - float(g[pre + "loss"])) < 1e-5

@@ -293,6 +293,27 @@ def test_vision_embed_kernels(dev, B, H, P, width):
     assert torch.equal(dpatch, d3[:, 1:].reshape(B * G, width).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("H,P", [(64, 32), (28, 14)])
+def test_patchify_uint8_input_fuses_totensor_normalize(dev, H, P):
+    """8f-4: uint8 pixels in either layout -> the same bf16 patch matrix as ToTensor + Normalize (constants.py:1-2)
+    followed by the float path (one bf16 rounding of a value computed with a fused multiply-add: <= 1 bf16 ulp apart)."""
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(H)
+    B = 3
+    u8 = torch.randint(0, 256, (B, 3, H, H), generator=g, dtype=torch.uint8)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    f = (u8.float() / 255.0 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    KP = 3 * P * P
+    Kpad = (KP + 63) // 64 * 64
+    ref = ops.patchify(f.to(dev), P, Kpad).float()
+    for hwc, src in ((False, u8), (True, u8.permute(0, 2, 3, 1).contiguous())):
+        got = ops.patchify_u8(src.to(dev), P, Kpad, mean, std, hwc).float()
+        assert float(got[:, KP:].abs().sum()) == 0.0
+        err = (got - ref).abs()
+        assert float((err / ref.abs().clamp_min(1e-3)).max()) <= 2.0 ** -7, (hwc, float(err.max()))
+        assert float((got != ref).float().mean()) < 0.02  # almost always the identical bf16 value
+
+
 def test_text_embed_and_pool_kernels(dev):
     from open_clip_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -379,6 +400,62 @@ def test_adamw_and_sumsq(dev):
     out = torch.zeros(1, device=dev)
     ops.sumsq_accum(gr, out)
     check("sumsq", out, (gr.double() ** 2).sum().float().reshape(1), rel=1e-5)
+
+
+def test_adamw_multi_fused_clip_and_operand_copies(dev):
+    """8f-1: one launch = clip_grad_norm_ + AdamW over every tensor + refresh of the bf16 GEMM-operand copies, against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (fp32; rel-L2 <= 1e-6, copies bit-equal to a cast of the result)."""
+    from open_clip_amd.model import _WeightCache
+    from open_clip_amd.optim import NativeAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(128, 192), (64, 64), (768,), (), (50, 768), (100003,), (192, 3, 8, 8), (24577,)]
+    ws = [torch.randn(sh, generator=g).to(dev) for sh in shapes]
+    P = [torch.nn.Parameter(w.clone()) for w in ws]
+    R = [torch.nn.Parameter(w.clone()) for w in ws]
+    wd_of = lambda p: 0.0 if p.ndim <= 1 else 0.2
+    ref = torch.optim.AdamW([{"params": [r], "weight_decay": wd_of(r), "lr": 5e-4 * (1 + i % 2)} for i, r in enumerate(R)],
+                            lr=5e-4, betas=(0.9, 0.98), eps=1e-6)
+    cache = _WeightCache()
+    for p in P:
+        if p.ndim in (2, 4):
+            cache.get(p, "n"), cache.get(p, "t")
+    opt = NativeAdamW([{"params": [p], "weight_decay": wd_of(p), "lr": 5e-4 * (1 + i % 2)} for i, p in enumerate(P)],
+                      lr=5e-4, betas=(0.9, 0.98), eps=1e-6, grad_clip_norm=0.7, weight_caches=[cache])
+    held = {id(p): (cache.peek(p, "n"), cache.peek(p, "t")) for p in P}
+    for step in range(3):
+        for i, (p, r) in enumerate(zip(P, R)):
+            gr = torch.randn(p.shape, generator=g).to(dev) * (0.1 + step)
+            r.grad = gr.clone()
+            if i in (0, 5):  # gradient views at a 4-byte offset (DDP bucket views): scalar path / unaligned tile path
+                buf = torch.empty(gr.numel() + 1, device=dev)
+                buf[1:].copy_(gr.flatten())
+                p.grad = buf[1:].view(p.shape)
+            else:
+                p.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_(R, 0.7)
+        ref.step()
+        opt.step()
+        check(f"adamw_multi grad-norm step {step}", opt.last_grad_norm_sq.sqrt(), total.reshape(1), rel=1e-5)
+    for i, (p, r) in enumerate(zip(P, R)):
+        check(f"adamw_multi param {tuple(p.shape)}", p.detach().reshape(-1), r.detach().reshape(-1), rel=1e-6)
+        if p.ndim in (2, 4):
+            n16, t16 = cache.get(p, "n"), cache.get(p, "t")
+            assert n16 is held[id(p)][0], "the optimizer must refresh the cached copy in place"
+            tileable = p.shape[0] % 64 == 0 and (p.numel() // p.shape[0]) % 64 == 0
+            assert (t16 is held[id(p)][1]) == tileable, "transposed copies of 64-divisible weights are refreshed in place, others re-cast"
+            w2 = p.detach().reshape(p.shape[0], -1)
+            assert torch.equal(n16, w2.to(torch.bfloat16)), tuple(p.shape)
+            assert torch.equal(t16, w2.t().contiguous().to(torch.bfloat16)), tuple(p.shape)
+    # the per-tensor path gives the same numbers
+    P2 = [torch.nn.Parameter(w.clone()) for w in ws[:4]]
+    o2 = NativeAdamW(P2, lr=5e-4, fused=False)
+    o3 = NativeAdamW([torch.nn.Parameter(w.clone()) for w in ws[:4]], lr=5e-4)
+    for a, b in zip(o2.param_groups[0]["params"], o3.param_groups[0]["params"]):
+        a.grad = torch.ones_like(a) * 0.3
+        b.grad = torch.ones_like(b) * 0.3
+    o2.step(), o3.step()
+    for a, b in zip(o2.param_groups[0]["params"], o3.param_groups[0]["params"]):
+        check("adamw fused vs per-tensor", b.detach().reshape(-1), a.detach().reshape(-1), rel=1e-7)
 
 
 def test_ops_fail_loudly_on_cpu_tensors(dev):

@@ -127,3 +127,59 @@ def test_full_size_properties_vitb32():
     with torch.no_grad():
         o2 = model(image=batch["image"].cuda(), text=batch["text"].cuda())
     assert torch.equal(o2["image_features"], out["image_features"]) and torch.equal(o2["text_features"], out["text_features"])
+
+
+def test_gradient_accumulation_path_matches_full_batch():
+    """8f-3: the reference's --accum-freq loop (train.py:236-311) over the native modules: features of every micro-batch
+    are cached under no_grad, then each micro-batch is re-run with gradient and the loss is taken over the concatenation
+    (cached features as negatives).  Tower gradients must equal the full-batch gradients; logit_scale receives one full
+    gradient PER micro-batch pass (the reference's behaviour, reproduced -- not normalised)."""
+    from open_clip_amd.loss import NativeClipLoss
+    from oracle import clip_oracle as O
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=31, perturb=True)
+    accum, Bm = 3, 4
+    batch = synthetic_batch(cfg, accum * Bm, seed=91)
+    outs, grads = O.train_forward_backward(batch["image"], batch["text"], state, cfg)
+    model = _build(cfg, state)
+    loss_fn = NativeClipLoss()
+    micro = [{"image": batch["image"][j * Bm:(j + 1) * Bm].cuda(), "text": batch["text"][j * Bm:(j + 1) * Bm].cuda()} for j in range(accum)]
+    feats = {"image_features": [], "text_features": []}
+    with torch.no_grad():
+        for mb in micro:
+            o = model(**mb)
+            for k in feats:
+                feats[k].append(o[k])
+    model.zero_grad(set_to_none=True)
+    for j, mb in enumerate(micro):
+        o = model(**mb)
+        inputs = {k: torch.cat(feats[k][:j] + [o[k]] + feats[k][j + 1:]) for k in feats}
+        losses = loss_fn(**inputs, logit_scale=o["logit_scale"], output_dict=True)
+        total = sum(v for k, v in losses.items() if k.endswith("_loss"))
+        total.backward()
+    torch.cuda.synchronize()
+    assert abs(float(total.detach()) - float(outs["loss"])) <= LOSS_TOL
+    gmax = max(float(v.norm()) for v in grads.values())
+    for k, p in model.named_parameters():
+        ref = grads[k] * (accum if k == "logit_scale" else 1)
+        rel = float((p.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        tol = GRAD_TOL if float(grads[k].norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        assert rel <= tol, (k, rel)
+
+
+def test_uint8_image_input_equals_normalised_float_input():
+    """8f-4 at the model boundary: NativeCLIP.encode_image(uint8 pixels) == encode_image(ToTensor+Normalize(pixels))."""
+    cfg = get_model_config("small-test")
+    model = _build(cfg, init_state_dict(cfg, seed=4, perturb=True))
+    S = cfg["vision_cfg"]["image_size"]
+    g = torch.Generator().manual_seed(8)
+    u8 = torch.randint(0, 256, (5, S, S, 3), generator=g, dtype=torch.uint8)  # decoder layout [B,H,W,3]
+    mean = torch.tensor(model.visual.image_mean).view(1, 3, 1, 1)
+    std = torch.tensor(model.visual.image_std).view(1, 3, 1, 1)
+    f = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    with torch.no_grad():
+        a = model.encode_image(u8.cuda(), normalize=True)
+        b = model.encode_image(u8.permute(0, 3, 1, 2).contiguous().cuda(), normalize=True)
+        c = model.encode_image(f.cuda(), normalize=True)
+    assert torch.equal(a, b)
+    assert float((a - c).abs().max()) <= 2e-3

@@ -35,4 +35,5 @@ for blk, base in ((0, 0), (133, 512)):
     t0 = t[0, 0]
     print(f"block {blk}: per tile [start, mainloop end, epilogue end] (us since first tile start)")
     for i in range(8):
-        print(f"  tile {i}: {float(t[i,0]-t0):8.2f} {float(t[i,3]-t0):8.2f} {float(t[i,4]-t0):8.2f}   main {float(t[i,3]-t[i,0]):6.2f}  epi {float(t[i,4]-t[i,3]):6.2f}")
+        print(f"  tile {i}: {float(t[i,0]-t0):8.2f} {float(t[i,3]-t0):8.2f} {float(t[i,4]-t0):8.2f}   main {float(t[i,3]-t[i,0]):6.2f}  epi {float(t[i,4]-t[i,3]):6.2f}"
+              f"  [bias + DMA drain {float(t[i,5]-t[i,3]):5.2f} | first half {float(t[i,6]-t[i,5]):5.2f} | second half {float(t[i,4]-t[i,6]):5.2f}]")

@@ -74,9 +74,80 @@ def attn_sweep():
         print(f"attn {name} L={L}: " + " | ".join(row) + f"   (bwd algorithmic {gb_b:.2f} GB)", flush=True)
 
 
+def attn_persist_sweep():
+    """attention backward as persistent workgroups (k per CU) started `st` us apart"""
+    for name, B, L, H, causal in [("img", 4096, 50, 12, False), ("txt", 4096, 77, 8, True)]:
+        C = H * 64
+        qkv = torch.randn(B * L, 3 * C, device=dev).bfloat16()
+        do = torch.randn(B * L, C, device=dev).bfloat16()
+        out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125)
+        ref = ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125)
+        ms0 = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
+        print(f"attn bwd {name} L={L}: one workgroup per item {ms0:.3f} ms", flush=True)
+        for k in (2, 3, 4, 6):
+            row = []
+            for st in (0, 2, 4, 6, 9, 12):
+                _lib.call("ocn_set_tuning", 2, k)
+                _lib.call("ocn_set_tuning", 3, st)
+                got = ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125)
+                ok = torch.equal(got, ref)
+                ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
+                row.append(f"st {st:2d}: {ms:.3f}{'' if ok else ' (MISMATCH)'}")
+            print(f"   {k} per CU: " + " | ".join(row), flush=True)
+        _lib.call("ocn_set_tuning", 2, 0)
+        _lib.call("ocn_set_tuning", 3, 0)
+
+
+def tn_sweep():
+    """weight-gradient kernel with and without its atomic epilogue"""
+    for name, M, N, K in [("img qkv", Mi, 2304, 768), ("img out", Mi, 768, 768), ("img fc", Mi, 3072, 768), ("img proj", Mi, 768, 3072),
+                          ("txt qkv", Mt, 1536, 512), ("txt out", Mt, 512, 512), ("txt fc", Mt, 2048, 512), ("txt proj", Mt, 512, 2048)]:
+        a = torch.randn(M, N, device=dev).bfloat16()
+        b = torch.randn(M, K, device=dev).bfloat16()
+        dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        row = []
+        for ab in (0, 1):
+            _lib.call("ocn_set_tuning", 4, ab)
+            ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
+            row.append(f"{'no-epilogue' if ab else 'full'} {ms:.3f} ms ({2.0 * M * N * K / ms / 1e9:5.0f} TF/s)")
+        _lib.call("ocn_set_tuning", 4, 0)
+        print(f"tn {name:9s} dW[{N},{K}]: " + " | ".join(row), flush=True)
+        del a, b
+
+
+def stagger_sweep():
+    """start-phase stagger of the persistent NT kernel (us per phase class; 63 = off, 0 = automatic)"""
+    cases = [("img fc", Mi, 3072, 768, [0, 1, 3]), ("img out", Mi, 768, 768, [2]), ("img proj", Mi, 768, 3072, [0, 2]),
+             ("txt fc", Mt, 2048, 512, [0, 1, 3]), ("txt out", Mt, 512, 512, [2]), ("txt proj", Mt, 512, 2048, [2]), ("img qkv", Mi, 2304, 768, [0])]
+    for name, M, N, K, epis in cases:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, device=dev)
+        for epi in epis:
+            f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
+            out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+            resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
+            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            row = []
+            for st in (63, 2, 4, 6, 8, 12, 0):
+                _lib.call("ocn_set_gemm_variant", 5 | (st << 21))
+                ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
+                row.append(f"st {st:2d}: {2.0 * M * N * K / ms / 1e9:5.0f}")
+            print(f"{name:9s} epi {epi} (TF/s): " + " | ".join(row), flush=True)
+            del out, resid, aux
+        del a, b
+    _lib.call("ocn_set_gemm_variant", 0)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "attn"):
         attn_sweep()
     if what in ("all", "nt"):
         nt_sweep()
+    if what in ("all", "stagger"):
+        stagger_sweep()
+    if what in ("all", "tn"):
+        tn_sweep()
+    if what in ("all", "attnp"):
+        attn_persist_sweep()
