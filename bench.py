@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--naive-global-loss", action="store_true", help="N>1: every rank evaluates the full N x N logits (the reference's "
+                    "redundant form) instead of its own rows (same loss and gradients; tests/test_dist_loss_gloo.py, test_ddp_gpu.py)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="developer: value for ocn_set_gemm_variant (kernel choice / ablation knobs)")
     ap.add_argument("--dist-backend", default="nccl", help="developer: 'gloo' + OCN_BENCH_ONE_DEVICE=1 runs N ranks on one GPU")
     return ap.parse_args()
@@ -148,7 +150,8 @@ def main():
         model.set_grad_checkpointing(True)
     B = args.local_batch
     batch = synthetic_batch(cfg, B, seed=1234, rank=rank, device=dev)
-    loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world)
+    loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
+                             row_sharded=(world > 1 and not args.naive_global_loss))
     opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
     if world > 1:
@@ -199,7 +202,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} CLIPTask-equivalent train step (fwd+ClipLoss+bwd+AdamW+clamp), amp_bf16 policy, "
                                    f"local_bs={B}, global_bs={B * world}, "
-                                   + ("gather_features all-gather + global logits" if world > 1 else "world_size 1 (no all-gather)"),
+                                   + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
+                                      if world > 1 else "world_size 1 (no all-gather)"),
                        "model": args.model, "global_batch": B * world, "local_batch": B, "parallelism": f"dp{world}",
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             "step_model_tflops_per_gpu": round(value / world * flops_pair / 1e3, 1),
@@ -207,9 +211,14 @@ def main():
         if not args.no_roofline:
             s = timer.summary()
             nt, tn = s["nt"], s["tn"]
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (all epilogues)", "achieved": round(nt["tflops"], 1),
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_stats.py from the PMC passes
+            if os.path.exists(tpath) and args.model == "ViT-B-32" and B == 4096:
+                rec = json.load(open(tpath))
+                traffic, traffic_src = round(rec["bytes_per_launch"]), rec["source"]
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt5_kernel (all epilogues)", "achieved": round(nt["tflops"], 1),
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(nt["tflops"] / PEAK_BF16_TFLOPS, 4),
-                                "traffic": None, "launches": nt["launches"], "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4),
+                                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "launches": nt["launches"], "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4),
                                 "algorithmic_tflop_per_launch_avg": round(nt["tflop"] / max(nt["launches"], 1), 4),
                                 "gemm_tn_kernel": {"achieved": round(tn["tflops"], 1), "frac": round(tn["tflops"] / PEAK_BF16_TFLOPS, 4),
                                                    "launches": tn["launches"], "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4)},

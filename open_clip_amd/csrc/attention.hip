@@ -176,31 +176,20 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-template <int MAXT>
-__global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+// WPE = waves per SIMD the register allocation is held to (2: up to 256 VGPRs; 3: 168 -- a handful of spills, but a third
+// 3-wave workgroup fits on a CU at the text tower's L = 77, where LDS would allow three and 236 VGPRs allow two)
+template <int MAXT, int WPE>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                         bf16* __restrict__ dqkv, int L, int H, int causal, float scale, int ablate,
-                                                         int nitems, int stagger) {
+                                                         bf16* __restrict__ dqkv, int L, int H, int causal, float scale, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int LP = nwaves * 32;
+    const int b = blockIdx.x / H, hd = blockIdx.x % H;
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
-    // Persistent form (gridDim.x < nitems): a workgroup walks items blockIdx.x, + gridDim.x, ... and the workgroups that share
-    // a CU start `stagger` ticks (100 MHz) apart, so that one is loading while another computes and a third stores -- launched
-    // together they move through load / compute / store in lockstep and the three phases simply add up (measured:
-    // profiles/r01_attn_bwd_ablation.txt).
-    if (stagger > 0) {
-        const int phase = (int)(blockIdx.x / 256u) & 3;
-        if (phase) {
-            const long long until = wall_clock64() + (long long)phase * stagger;
-            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = item / H, hd = item % H;
     const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
     const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
     const bf16* obase = out + (size_t)b * L * C + hd * 64;
@@ -326,8 +315,6 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_kernel(const bf16* __restrict__
             flush_tile(sdO, wave * 32, lane, dbase + 2 * C, rs, L);
         }
     }
-    __syncthreads();  // the images are re-staged by the next item
-    }
 }
 
 int check_attn(const char* name, int B, int L, int H) {
@@ -365,29 +352,34 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
     OCN_CHECK_ARG(qkv && out && dout && lse && dqkv, "ocn_attn_bwd: null operand");
     if (int e = check_attn("ocn_attn_bwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
-    const int lds = 4 * nw * 32 * 128 + 2 * nw * 32 * 4;
+    int lds = 4 * nw * 32 * 128 + 2 * nw * 32 * 4;
     OCN_CHECK_ARG(lds <= 160 * 1024, "ocn_attn_bwd: L=%d needs %d bytes of LDS (> 160 KiB)", L, lds);
-    // developer knobs: tuning[2] = persistent workgroups per CU (0 = one workgroup per item), tuning[3] = stagger in us
-    const int nitems = B * H;
-    int grid = nitems;
-    if (g_ocn_tuning[2] > 0 && nitems > 256 * g_ocn_tuning[2]) grid = 256 * g_ocn_tuning[2];
-    const int stagger = grid < nitems ? g_ocn_tuning[3] * 100 : 0;
-    if (nw <= 4) {
+    if (g_ocn_tuning[5] > 0 && lds + g_ocn_tuning[5] * 1024 <= 160 * 1024) lds += g_ocn_tuning[5] * 1024;  // developer knob: lower the occupancy
+    const bool three = (nw == 3) ? (g_ocn_tuning[2] != 2) : (g_ocn_tuning[2] == 3);  // developer knob 2: force 2 / 3 waves per SIMD
+    if (nw <= 4 && three) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(attn_bwd_kernel<256>, dim3(grid), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1], nitems, stagger);
+        hipLaunchKernelGGL((attn_bwd_kernel<256, 3>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
+    } else if (nw <= 4) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_kernel<256, 2>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<640, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(attn_bwd_kernel<640>, dim3(grid), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1], nitems, stagger);
+        hipLaunchKernelGGL((attn_bwd_kernel<640, 1>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
     }
     OCN_CHECK_LAUNCH("ocn_attn_bwd");
     return OCN_OK;

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // columns and the band's B panels (band x 256 x K bf16) stay resident in that XCD's 4 MiB L2 while the A panels stream
     // through once per band.  Row-major over all of N (band = tiles_n) re-reads the whole of B once per round of tiles when
     // B does not fit in L2 next to the A panels: measured 1.74 GB of L2-miss reads per launch instead of 0.32 GB on the
-    // [204800 x 3072 x 768] GEMM (profiles/r01_pmc_hbm_traffic.txt).
+    // [204800 x 3072 x 768] GEMM (profiles/r01_pmc_hbm_traffic_before_band.txt).
     const int tiles_m = a.ntiles / a.tiles_n;
     const int band_tiles = tiles_m * a.band;
     auto tile_origin = [&](int i, int& m0, int& n0) {

@@ -48,7 +48,9 @@ def _worker(rank, port, mode, outdir):
     model.load_state_dict(state)
     model = model.cuda().train()
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=1, gradient_as_bucket_view=True)
-    kw = dict(local_loss=False, gather_with_grad=False) if mode == "global" else dict(local_loss=True, gather_with_grad=True)
+    kw = {"global": dict(local_loss=False, gather_with_grad=False),
+          "global_rowsharded": dict(local_loss=False, gather_with_grad=False, row_sharded=True),
+          "local_gwg": dict(local_loss=True, gather_with_grad=True)}[mode]
     loss_fn = NativeClipLoss(rank=rank, world_size=WORLD, **kw)
     lo, hi = rank * B_LOCAL, (rank + 1) * B_LOCAL
     losses = []
@@ -65,7 +67,7 @@ def _worker(rank, port, mode, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["global", "local_gwg"])
+@pytest.mark.parametrize("mode", ["global", "global_rowsharded", "local_gwg"])
 def test_two_ranks_ddp_against_full_batch_oracle(mode, tmp_path):
     import torch.multiprocessing as mp
     from open_clip_amd.configs import get_model_config
@@ -80,7 +82,7 @@ def test_two_ranks_ddp_against_full_batch_oracle(mode, tmp_path):
     r = [np.load(os.path.join(str(tmp_path), f"rank{i}.npz")) for i in range(WORLD)]
     for i in range(WORLD):
         assert abs(r[i]["loss"][0] - r[i]["loss"][1]) < 1e-5, "the two passes must agree (same weights, same data)"
-    if mode == "global":
+    if mode.startswith("global"):  # the row-sharded evaluation must be indistinguishable from the redundant one
         for i in range(WORLD):
             assert abs(float(r[i]["loss"][1]) - float(ref["loss"])) < 2e-2, (r[i]["loss"], float(ref["loss"]))
         gscale = 1.0 / WORLD
@@ -93,5 +95,7 @@ def test_two_ranks_ddp_against_full_batch_oracle(mode, tmp_path):
         # logit_scale: in the global mode every rank evaluates the FULL loss, so each holds the full d/ds and the DDP mean
         # leaves it unscaled (only the feature gradients are restricted to the local slice, loss.py:47-50)
         want = rgrads[k] * (1.0 if k == "logit_scale" else gscale)
+        if mode == "global_rowsharded" and k == "logit_scale":
+            pass  # every rank holds the all-reduced (full) d/ds, exactly as in the redundant evaluation
         rel = float((g0 - want).norm() / want.norm().clamp_min(1e-12))
         assert rel < 6e-2, (mode, k, rel)

@@ -39,6 +39,17 @@ def main():
     for tot, n, rd, wr, us, k in sorted(rows, reverse=True)[:40]:
         print(f"{n:6d} {rd:15.1f} {wr:16.1f} {rd + wr:16.1f} {us:16.1f}  {k}")
     print(f"# total HBM traffic of the run: {sum(r[0] for r in rows) / 1e3:.1f} GB")
+    if len(sys.argv) > 3:  # machine-readable record of the dominant kernel family for bench.py's roofline.traffic
+        import json
+        fam = [r for r in rows if r[5].startswith("gemm_nt5_kernel")]
+        n = sum(r[1] for r in fam)
+        rec = {"kernel": "gemm_nt5_kernel (all epilogues)", "launches": n,
+               "read_bytes_per_launch": sum(r[2] * r[1] for r in fam) * 1e6 / n,
+               "write_bytes_per_launch": sum(r[3] * r[1] for r in fam) * 1e6 / n,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1`; "
+                         "FETCH_SIZE doubled (gfx950 counts 128-byte requests at 64 B), KiB units"}
+        rec["bytes_per_launch"] = rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]
+        json.dump(rec, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":

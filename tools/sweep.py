@@ -74,28 +74,32 @@ def attn_sweep():
         print(f"attn {name} L={L}: " + " | ".join(row) + f"   (bwd algorithmic {gb_b:.2f} GB)", flush=True)
 
 
-def attn_persist_sweep():
-    """attention backward as persistent workgroups (k per CU) started `st` us apart"""
+def attn_wpe_sweep():
+    """attention backward held to 2 / 3 waves per SIMD (register budget 256 / 168)"""
     for name, B, L, H, causal in [("img", 4096, 50, 12, False), ("txt", 4096, 77, 8, True)]:
         C = H * 64
         qkv = torch.randn(B * L, 3 * C, device=dev).bfloat16()
         do = torch.randn(B * L, C, device=dev).bfloat16()
         out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125)
-        ref = ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125)
-        ms0 = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
-        print(f"attn bwd {name} L={L}: one workgroup per item {ms0:.3f} ms", flush=True)
-        for k in (2, 3, 4, 6):
-            row = []
-            for st in (0, 2, 4, 6, 9, 12):
-                _lib.call("ocn_set_tuning", 2, k)
-                _lib.call("ocn_set_tuning", 3, st)
-                got = ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125)
-                ok = torch.equal(got, ref)
-                ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
-                row.append(f"st {st:2d}: {ms:.3f}{'' if ok else ' (MISMATCH)'}")
-            print(f"   {k} per CU: " + " | ".join(row), flush=True)
+        row, ref = [], None
+        for wpe in (2, 3, 0):
+            _lib.call("ocn_set_tuning", 2, wpe)
+            got = ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125)
+            ref = got if ref is None else ref
+            ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
+            row.append(f"wpe {wpe}: {ms:.3f} ms{'' if torch.equal(got, ref) else ' (MISMATCH)'}")
         _lib.call("ocn_set_tuning", 2, 0)
-        _lib.call("ocn_set_tuning", 3, 0)
+        print(f"attn bwd {name} L={L}: " + " | ".join(row), flush=True)
+        row = []
+        for extra_kb in (0, 8, 20, 45):  # fewer resident workgroups per CU: does the arithmetic-only time scale with occupancy?
+            _lib.call("ocn_set_tuning", 5, extra_kb)
+            for mask in (0, 5):
+                _lib.call("ocn_set_tuning", 1, mask)
+                ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
+                row.append(f"+{extra_kb}KB LDS {'compute-only' if mask else 'full'} {ms:.3f}")
+        _lib.call("ocn_set_tuning", 5, 0)
+        _lib.call("ocn_set_tuning", 1, 0)
+        print("     occupancy probe: " + " | ".join(row), flush=True)
 
 
 def tn_sweep():
@@ -147,7 +151,7 @@ if __name__ == "__main__":
         nt_sweep()
     if what in ("all", "stagger"):
         stagger_sweep()
+    if what in ("all", "attnw"):
+        attn_wpe_sweep()
     if what in ("all", "tn"):
         tn_sweep()
-    if what in ("all", "attnp"):
-        attn_persist_sweep()
