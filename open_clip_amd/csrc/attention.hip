@@ -193,60 +193,68 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
     const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
     const bf16* obase = out + (size_t)b * L * C + hd * 64;
-    char* sQ = smem;
-    char* sK = smem + LP * 128;
-    char* sV = smem + 2 * LP * 128;
-    char* sdO = smem + 3 * LP * 128;
-    float* sLse = (float*)(smem + 4 * LP * 128);
+    // Two-pass staging (3 images instead of 4): the arithmetic of this kernel is latency-bound and its rate scales with the
+    // number of resident workgroups (measured: profiles/r01_attn_bwd_occupancy.txt), and LDS is what caps that number.  Pass 1
+    // holds K and V (dQ needs all keys; the wave's own Q / dO / O rows come straight from global memory into fragments),
+    // pass 2 re-uses the two images for Q and dO (dK / dV need all queries; the wave's own K / V fragments were taken from
+    // the images before they were overwritten).  The third image is the transposing buffer of dQ, so that its stores and the
+    // pass-2 LDS-DMA overlap.
+    char* sA = smem;                  // K, then Q, then the transposing buffer of dK
+    char* sB = smem + LP * 128;       // V, then dO, then the transposing buffer of dV
+    char* sC = smem + 2 * LP * 128;   // transposing buffer of dQ
+    float* sLse = (float*)(smem + 3 * LP * 128);
     float* sDelta = sLse + LP;
-    if (!(ablate & 1)) {
-    stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
-    stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
-    stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
-    stage_head(dobase, (size_t)C, L, LP, sdO, wave, nwaves, lane);
-    }
-    // delta[q] = sum_d dO[q,d] * O[q,d]; lse in exp2 units
-    for (int idx = threadIdx.x; idx < ((ablate & 1) ? 0 : LP * 8); idx += blockDim.x) {
-        const int r = idx >> 3, c = idx & 7;
-        const int gr = r < L ? r : L - 1;
-        const bf16x8 a = *(const bf16x8*)(dobase + (size_t)gr * C + c * 8);
-        const bf16x8 o = *(const bf16x8*)(obase + (size_t)gr * C + c * 8);
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d += bf2f(a[e]) * bf2f(o[e]);
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
-        if (c == 0) {
-            sDelta[r] = d;
-            sLse[r] = lse[((size_t)b * H + hd) * L + gr] * LOG2E;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int lr = lane & 31, lh = lane >> 5;
     const float sc = scale * LOG2E;
+    if (!(ablate & 1)) {
+        stage_head(qbase + C, rs, L, LP, sA, wave, nwaves, lane);
+        stage_head(qbase + 2 * C, rs, L, LP, sB, wave, nwaves, lane);
+    }
 
     // ---- phase A: dQ for query block `wave` (lane <-> query, registers <-> keys) ----
     f32x16 dq0 = zero16(), dq1 = zero16();
     {
         const int qb = wave;
         const int query = qb * 32 + lr;
-        const float lse_q = sLse[query], delta_q = sDelta[query];
+        const int qrow = query < L ? query : L - 1;  // rows >= L: copies of row L-1 (masked below)
         bf16x8 qf[4], dof[4];
+        float lse_q = 0.f, delta_q = 0.f;
+        if (!(ablate & 1)) {
+            // this lane's 8 d's of k-step s are columns (2s + lh)*8 .. +7 of its query's row
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            qf[s] = frag_rows(sQ, query, s, lane);
-            dof[s] = frag_rows(sdO, query, s, lane);
+            for (int s = 0; s < 4; ++s) {
+                qf[s] = *(const bf16x8*)(qbase + (size_t)qrow * rs + (s * 2 + lh) * 8);
+                dof[s] = *(const bf16x8*)(dobase + (size_t)qrow * C + (s * 2 + lh) * 8);
+            }
+            // delta[q] = sum_d dO[q,d] * O[q,d] (each half-wave holds 32 of the 64 d's); lse in exp2 units
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 o = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(o[e]);
+            }
+            delta_q += __shfl_xor(delta_q, 32, 64);
+            lse_q = lse[((size_t)b * H + hd) * L + qrow] * LOG2E;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qf[s] = frag_rows(sA, query, s, lane);
+                dof[s] = frag_rows(sB, query, s, lane);
+            }
         }
+        if (lh == 0) {  // phase B reads these for every query
+            sLse[query] = lse_q;
+            sDelta[query] = delta_q;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         const int nkb = (ablate & 2) ? 0 : (causal ? qb + 1 : nwaves);
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st = mfma32(frag_rows(sK, kb * 32 + lr, s, lane), qf[s], st);
-                dp = mfma32(frag_rows(sV, kb * 32 + lr, s, lane), dof[s], dp);
+                st = mfma32(frag_rows(sA, kb * 32 + lr, s, lane), qf[s], st);
+                dp = mfma32(frag_rows(sB, kb * 32 + lr, s, lane), dof[s], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bf16x8 dsf = pack8(st, t);
-                dq0 = mfma32(frag_cols(sK, kb * 32, t, 0, lane), dsf, dq0);
-                dq1 = mfma32(frag_cols(sK, kb * 32, t, 1, lane), dsf, dq1);
+                dq0 = mfma32(frag_cols(sA, kb * 32, t, 0, lane), dsf, dq0);
+                dq1 = mfma32(frag_cols(sA, kb * 32, t, 1, lane), dsf, dq1);
             }
         }
     }
@@ -271,23 +279,29 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            kf[s] = frag_rows(sK, key, s, lane);
-            vf[s] = frag_rows(sV, key, s, lane);
+            kf[s] = frag_rows(sA, key, s, lane);
+            vf[s] = frag_rows(sB, key, s, lane);
         }
-        // every wave has finished phase A and holds its K / V fragments: the K image is free -> dQ leaves through it now
-        // (keeping dQ in registers across phase B would cost the second wave per SIMD)
+        // every wave has finished phase A and holds its K / V fragments: the two images are re-staged with Q and dO while dQ
+        // leaves through the third one (keeping dQ in registers across phase B would cost occupancy)
         __syncthreads();
         bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
-        stage_tile(sK, wave * 32, lane, dq0, dq1, 1.0f);
-        if (!(ablate & 4)) flush_tile(sK, wave * 32, lane, dbase, rs, L);
+        if (!(ablate & 1)) {
+            stage_head(qbase, rs, L, LP, sA, wave, nwaves, lane);
+            stage_head(dobase, (size_t)C, L, LP, sB, wave, nwaves, lane);
+        }
+        stage_tile(sC, wave * 32, lane, dq0, dq1, 1.0f);
+        if (!(ablate & 4)) flush_tile(sC, wave * 32, lane, dbase, rs, L);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
         const int qb0 = (ablate & 2) ? nwaves : (causal ? kb : 0);
         for (int qb = qb0; qb < nwaves; ++qb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st = mfma32(frag_rows(sQ, qb * 32 + lr, s, lane), kf[s], st);
-                dp = mfma32(frag_rows(sdO, qb * 32 + lr, s, lane), vf[s], dp);
+                st = mfma32(frag_rows(sA, qb * 32 + lr, s, lane), kf[s], st);
+                dp = mfma32(frag_rows(sB, qb * 32 + lr, s, lane), vf[s], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -300,19 +314,19 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bf16x8 pf = pack8(st, t), dsf = pack8(dp, t);
-                dv0 = mfma32(frag_cols(sdO, qb * 32, t, 0, lane), pf, dv0);
-                dv1 = mfma32(frag_cols(sdO, qb * 32, t, 1, lane), pf, dv1);
-                dk0 = mfma32(frag_cols(sQ, qb * 32, t, 0, lane), dsf, dk0);
-                dk1 = mfma32(frag_cols(sQ, qb * 32, t, 1, lane), dsf, dk1);
+                dv0 = mfma32(frag_cols(sB, qb * 32, t, 0, lane), pf, dv0);
+                dv1 = mfma32(frag_cols(sB, qb * 32, t, 1, lane), pf, dv1);
+                dk0 = mfma32(frag_cols(sA, qb * 32, t, 0, lane), dsf, dk0);
+                dk1 = mfma32(frag_cols(sA, qb * 32, t, 1, lane), dsf, dk1);
             }
         }
         // every wave is done with the Q / dO images: they become the transposing buffers of dK / dV
         __syncthreads();
-        stage_tile(sQ, wave * 32, lane, dk0, dk1, 1.0f);
-        stage_tile(sdO, wave * 32, lane, dv0, dv1, 1.0f);
+        stage_tile(sA, wave * 32, lane, dk0, dk1, 1.0f);
+        stage_tile(sB, wave * 32, lane, dv0, dv1, 1.0f);
         if (!(ablate & 4)) {
-            flush_tile(sQ, wave * 32, lane, dbase + C, rs, L);
-            flush_tile(sdO, wave * 32, lane, dbase + 2 * C, rs, L);
+            flush_tile(sA, wave * 32, lane, dbase + C, rs, L);
+            flush_tile(sB, wave * 32, lane, dbase + 2 * C, rs, L);
         }
     }
 }
@@ -352,10 +366,10 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
     OCN_CHECK_ARG(qkv && out && dout && lse && dqkv, "ocn_attn_bwd: null operand");
     if (int e = check_attn("ocn_attn_bwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
-    int lds = 4 * nw * 32 * 128 + 2 * nw * 32 * 4;
+    int lds = 3 * nw * 32 * 128 + 2 * nw * 32 * 4;
     OCN_CHECK_ARG(lds <= 160 * 1024, "ocn_attn_bwd: L=%d needs %d bytes of LDS (> 160 KiB)", L, lds);
     if (g_ocn_tuning[5] > 0 && lds + g_ocn_tuning[5] * 1024 <= 160 * 1024) lds += g_ocn_tuning[5] * 1024;  // developer knob: lower the occupancy
-    const bool three = (nw == 3) ? (g_ocn_tuning[2] != 2) : (g_ocn_tuning[2] == 3);  // developer knob 2: force 2 / 3 waves per SIMD
+    const bool three = g_ocn_tuning[2] == 3;  // developer knob 2 = 3: the 168-VGPR build (3 waves per SIMD, ~22 spilled registers; measured no faster: profiles/r01_attn_bwd_two_pass.txt)
     if (nw <= 4 && three) {
         static bool attr_set = false;
         if (!attr_set) {
