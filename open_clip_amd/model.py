@@ -77,11 +77,69 @@ def _publish_twin(g32, g16):
     _GRAD_TWINS[g32.data_ptr()] = (g32.shape, g32._version, g16)
 
 
+def _drop_twins():
+    """called where a tower's backward chain starts (head) and ends (embedding): a hand-off that nobody took must not
+    outlive its chain -- the registry is keyed by address, and the allocator re-uses addresses from step to step"""
+    _GRAD_TWINS.clear()
+
+
 def _take_twin(g32):
     hit = _GRAD_TWINS.pop(g32.data_ptr(), None)
     if hit is not None and hit[0] == g32.shape and hit[1] == g32._version:
         return hit[2]
     return ops.cast_bf16(g32)
+
+
+# ------------------------------------------------------------------------------------------------------
+# weight-gradient GEMMs under the HBM-bound kernels of the backward.  In a block's backward the four wgrad GEMMs
+# (MFMA-bound; 128 KiB of LDS and 2 waves per SIMD on every CU) feed nothing but .grad, while the chain that produces the
+# next block's input gradient alternates NT GEMMs with HBM-bound kernels -- two LayerNorm backwards and the attention
+# backward -- whose workgroups fit NEXT TO a wgrad workgroup on the same CU (18-25 KiB of LDS, one more wave per SIMD).
+# So each HBM-bound kernel is paired with wgrad work on a second HIP stream:
+#     main:  dGELU GEMM, dh2 GEMM | LN2 bwd     | da GEMM | attention bwd | dh1 GEMM | LN1 bwd
+#     side:                       | wgrad proj  |         | wgrad fc      |          | wgrad out, wgrad qkv
+# with a fork (side waits for main) before and a join (main waits for side) after every pairing: the persistent NT GEMMs
+# never share the chip with a wgrad (two MFMA-bound kernels only take CUs from each other, and a persistent kernel whose
+# workgroups start late ends late), and the block's gradients are complete on the main stream when they are handed to
+# autograd (DDP hooks / the optimizer run there).  OCN_WGRAD_STREAM=0 keeps everything on one stream.
+# ------------------------------------------------------------------------------------------------------
+import os as _os
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    if _os.environ.get("OCN_WGRAD_STREAM", "1") == "0":
+        return None
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+class _Paired:
+    """``with _Paired(dev) as side: side(fn, ...)`` enqueues fn on the side stream after everything already on the main
+    stream; leaving the block joins the side stream back into the main stream."""
+
+    def __init__(self, dev):
+        self.side = _side_stream(dev)
+        self.main = torch.cuda.current_stream(dev) if self.side is not None else None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+        return self
+
+    def __call__(self, fn, *args):
+        if self.side is None:
+            return fn(*args)
+        with torch.cuda.stream(self.side):
+            return fn(*args)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+        return False
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -138,19 +196,23 @@ class _BlockFn(torch.autograd.Function):
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
 
         dy16 = _take_twin(dy)
+        dev = x.device
         # ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid)))) ----
         df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
-        ops.gemm_tn_accum(dy16, g, dwproj, dbproj)
         dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
-        ops.gemm_tn_accum(df, h2, dwfc, dbfc)
-        dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
+        with _Paired(dev) as side:
+            side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj)
+            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
-        ops.gemm_tn_accum(dxmid16, a, dwo, dbo)
-        dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, 64 ** -0.5)
+        with _Paired(dev) as side:
+            side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
+            dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, 64 ** -0.5)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
-        ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv)
-        dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True)
+        with _Paired(dev) as side:
+            side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo)
+            side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True)
         _publish_twin(dx, dx16)
         return (dx, *grads, None, None, None, None, None, None)
 
@@ -187,6 +249,7 @@ class _VisionEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx0):
+        _drop_twins()
         patches, emb, mean, rstd, lnw, conv_w, cls, pos = ctx.saved_tensors
         B, G, width, KP, Kpad = ctx.meta
         dev = emb.device
@@ -212,6 +275,7 @@ class _TextEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx):
+        _drop_twins()
         text, table, pos = ctx.saved_tensors
         dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
         ops.token_embed_bwd(text.contiguous(), dx.contiguous(), dtable, dpos)
@@ -251,7 +315,10 @@ class _HeadFn(torch.autograd.Function):
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
         dpooled, _ = ops.layernorm_bwd(dp16, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
         dx = torch.zeros(xshape, dtype=F32, device=dy.device)
-        ops.scatter_rows(dpooled, idx, dx, B, L)
+        dx16 = torch.zeros(xshape, dtype=BF16, device=dy.device)  # bf16 twin for the last block's dgrad / wgrad GEMMs
+        ops.scatter_rows(dpooled, idx, dx, B, L, dx16)
+        _drop_twins()
+        _publish_twin(dx, dx16)
         return dx, dlnw, dlnb, dproj, None, None, None, None, None
 
 

@@ -200,9 +200,9 @@ def gather_rows(x, idx, B, L):
     return out
 
 
-def scatter_rows(d, idx, dx, B, L):
+def scatter_rows(d, idx, dx, B, L, dx16=None):
     C = d.shape[1]
-    _lib.call("ocn_scatter_rows", _chk(d, F32, "d"), _chk(idx, torch.int32, "idx"), _chk(dx, F32, "dx"), 0, B, L, C, _stream())
+    _lib.call("ocn_scatter_rows", _chk(d, F32, "d"), _chk(idx, torch.int32, "idx"), _chk(dx, F32, "dx"), _chk(dx16, BF16, "dx16"), B, L, C, _stream())
     return dx
 
 

@@ -183,3 +183,52 @@ def test_uint8_image_input_equals_normalised_float_input():
         c = model.encode_image(f.cuda(), normalize=True)
     assert torch.equal(a, b)
     assert float((a - c).abs().max()) <= 2e-3
+
+
+def test_vitl14_grad_checkpointed_step_against_cpu_oracle():
+    """BASELINE config 4's model (ViT-L-14: patch 14 -> K padded 588 -> 640, 257 image tokens -> the 9-wave attention
+    kernels, 24 + 12 blocks, embed 768) with set_grad_checkpointing, small batch, against the CPU oracle."""
+    from oracle import clip_oracle as O
+    cfg = get_model_config("ViT-L-14")
+    state = init_state_dict(cfg, seed=2, perturb=True)
+    batch = synthetic_batch(cfg, 3, seed=13)
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    outs, grads = O.train_forward_backward(batch["image"], batch["text"], state, cfg)
+    model = _build(cfg, state)
+    model.set_grad_checkpointing(True)
+    out, loss = _step(model, batch)
+    fi = float((out["image_features"].float().cpu() - outs["image_features"]).abs().max())
+    ft = float((out["text_features"].float().cpu() - outs["text_features"]).abs().max())
+    _report(f"oracle[ViT-L-14,B3,ckpt]: feat max_abs {fi:.3e}/{ft:.3e} loss {float(loss):.6f} vs {float(outs['loss']):.6f}")
+    assert fi <= FEAT_TOL and ft <= FEAT_TOL
+    assert abs(float(loss) - float(outs["loss"])) <= LOSS_TOL
+    gmax = max(float(v.norm()) for v in grads.values())
+    keys = ["visual.conv1.weight", "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.23.mlp.c_fc.weight",
+            "visual.transformer.resblocks.11.ln_1.weight", "transformer.resblocks.0.mlp.c_proj.weight", "token_embedding.weight",
+            "text_projection", "visual.proj", "visual.positional_embedding", "logit_scale"]
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = grads[k]
+        rel = float((named[k].grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        tol = GRAD_TOL if float(ref.norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        _report(f"oracle[ViT-L-14]:   grad rel_l2={rel:.3e} |g|={float(ref.norm()):.3e} {k}")
+        assert rel <= tol, (k, rel)
+
+
+def test_state_carried_between_steps_is_not_stale():
+    """The per-step caches (bf16 weight copies, the bf16 hand-off of the residual-stream gradient between blocks, allocator-
+    recycled addresses) must not leak from one step into the next: gradients of a second step on NEW data equal those of a
+    fresh model given only that data (fp32 atomics order aside)."""
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=17, perturb=True)
+    a, b = synthetic_batch(cfg, 8, seed=1), synthetic_batch(cfg, 8, seed=2)
+    m1 = _build(cfg, state)
+    _step(m1, a)
+    m1.zero_grad(set_to_none=True)
+    _, l1 = _step(m1, b)
+    m2 = _build(cfg, state)
+    _, l2 = _step(m2, b)
+    assert abs(float(l1.detach()) - float(l2.detach())) < 1e-6
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        rel = float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-30))
+        assert rel < 1e-4, (k, rel)
