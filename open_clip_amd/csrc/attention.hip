@@ -193,15 +193,15 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
     const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
     const bf16* obase = out + (size_t)b * L * C + hd * 64;
-    // Two-pass staging (3 images instead of 4): the arithmetic of this kernel is latency-bound and its rate scales with the
-    // number of resident workgroups (measured: profiles/r01_attn_bwd_occupancy.txt), and LDS is what caps that number.  Pass 1
-    // holds K and V (dQ needs all keys; the wave's own Q / dO / O rows come straight from global memory into fragments),
-    // pass 2 re-uses the two images for Q and dO (dK / dV need all queries; the wave's own K / V fragments were taken from
-    // the images before they were overwritten).  The third image is the transposing buffer of dQ, so that its stores and the
-    // pass-2 LDS-DMA overlap.
+    // Three images instead of four: the arithmetic of this kernel is latency-bound and its rate scales with the number of
+    // resident workgroups (measured: profiles/r01_attn_bwd_occupancy.txt), and LDS is what caps that number.  Pass 1 holds K,
+    // V and dO (dQ needs all keys; the wave's own Q and O rows come straight from global memory into fragments); before pass 2
+    // (dK / dV need all queries) Q is staged over K while dQ leaves through the V image -- the wave's own K / V fragments are
+    // taken from the images first -- so the only load a workgroup waits for in mid-flight is one image, issued together with
+    // the dQ stores.
     char* sA = smem;                  // K, then Q, then the transposing buffer of dK
-    char* sB = smem + LP * 128;       // V, then dO, then the transposing buffer of dV
-    char* sC = smem + 2 * LP * 128;   // transposing buffer of dQ
+    char* sB = smem + LP * 128;       // V, then the transposing buffer of dQ
+    char* sC = smem + 2 * LP * 128;   // dO, then the transposing buffer of dV
     float* sLse = (float*)(smem + 3 * LP * 128);
     float* sDelta = sLse + LP;
     const int lr = lane & 31, lh = lane >> 5;
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     if (!(ablate & 1)) {
         stage_head(qbase + C, rs, L, LP, sA, wave, nwaves, lane);
         stage_head(qbase + 2 * C, rs, L, LP, sB, wave, nwaves, lane);
+        stage_head(dobase, (size_t)C, L, LP, sC, wave, nwaves, lane);
     }
 
     // ---- phase A: dQ for query block `wave` (lane <-> query, registers <-> keys) ----
@@ -217,37 +218,37 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         const int qb = wave;
         const int query = qb * 32 + lr;
         const int qrow = query < L ? query : L - 1;  // rows >= L: copies of row L-1 (masked below)
-        bf16x8 qf[4], dof[4];
+        bf16x8 qf[4], dof[4], of[4];
         float lse_q = 0.f, delta_q = 0.f;
         if (!(ablate & 1)) {
             // this lane's 8 d's of k-step s are columns (2s + lh)*8 .. +7 of its query's row
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 qf[s] = *(const bf16x8*)(qbase + (size_t)qrow * rs + (s * 2 + lh) * 8);
-                dof[s] = *(const bf16x8*)(dobase + (size_t)qrow * C + (s * 2 + lh) * 8);
+                of[s] = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
             }
-            // delta[q] = sum_d dO[q,d] * O[q,d] (each half-wave holds 32 of the 64 d's); lse in exp2 units
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 o = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(o[e]);
-            }
-            delta_q += __shfl_xor(delta_q, 32, 64);
-            lse_q = lse[((size_t)b * H + hd) * L + qrow] * LOG2E;
+            lse_q = lse[((size_t)b * H + hd) * L + qrow] * LOG2E;  // exp2 units
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 qf[s] = frag_rows(sA, query, s, lane);
-                dof[s] = frag_rows(sB, query, s, lane);
+                of[s] = qf[s];
             }
-        }
-        if (lh == 0) {  // phase B reads these for every query
-            sLse[query] = lse_q;
-            sDelta[query] = delta_q;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // delta[q] = sum_d dO[q,d] * O[q,d] (each half-wave holds 32 of the 64 d's)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            dof[s] = frag_rows(sC, query, s, lane);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[s][e]);
+        }
+        delta_q += __shfl_xor(delta_q, 32, 64);
+        if (lh == 0) {  // phase B (behind the next barrier) reads these for every query
+            sLse[query] = lse_q;
+            sDelta[query] = delta_q;
+        }
         const int nkb = (ablate & 2) ? 0 : (causal ? qb + 1 : nwaves);
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16 st = zero16(), dp = zero16();
@@ -282,16 +283,13 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             kf[s] = frag_rows(sA, key, s, lane);
             vf[s] = frag_rows(sB, key, s, lane);
         }
-        // every wave has finished phase A and holds its K / V fragments: the two images are re-staged with Q and dO while dQ
-        // leaves through the third one (keeping dQ in registers across phase B would cost occupancy)
+        // every wave has finished phase A and holds its K / V fragments: Q is staged over K while dQ leaves through the V
+        // image (keeping dQ in registers across phase B would cost occupancy)
         __syncthreads();
         bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
-        if (!(ablate & 1)) {
-            stage_head(qbase, rs, L, LP, sA, wave, nwaves, lane);
-            stage_head(dobase, (size_t)C, L, LP, sB, wave, nwaves, lane);
-        }
-        stage_tile(sC, wave * 32, lane, dq0, dq1, 1.0f);
-        if (!(ablate & 4)) flush_tile(sC, wave * 32, lane, dbase, rs, L);
+        if (!(ablate & 1)) stage_head(qbase, rs, L, LP, sA, wave, nwaves, lane);
+        stage_tile(sB, wave * 32, lane, dq0, dq1, 1.0f);
+        if (!(ablate & 4)) flush_tile(sB, wave * 32, lane, dbase, rs, L);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 st = mfma32(frag_rows(sA, qb * 32 + lr, s, lane), kf[s], st);
-                dp = mfma32(frag_rows(sB, qb * 32 + lr, s, lane), vf[s], dp);
+                dp = mfma32(frag_rows(sC, qb * 32 + lr, s, lane), vf[s], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -314,8 +312,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bf16x8 pf = pack8(st, t), dsf = pack8(dp, t);
-                dv0 = mfma32(frag_cols(sB, qb * 32, t, 0, lane), pf, dv0);
-                dv1 = mfma32(frag_cols(sB, qb * 32, t, 1, lane), pf, dv1);
+                dv0 = mfma32(frag_cols(sC, qb * 32, t, 0, lane), pf, dv0);
+                dv1 = mfma32(frag_cols(sC, qb * 32, t, 1, lane), pf, dv1);
                 dk0 = mfma32(frag_cols(sA, qb * 32, t, 0, lane), dsf, dk0);
                 dk1 = mfma32(frag_cols(sA, qb * 32, t, 1, lane), dsf, dk1);
             }
@@ -323,11 +321,143 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         // every wave is done with the Q / dO images: they become the transposing buffers of dK / dV
         __syncthreads();
         stage_tile(sA, wave * 32, lane, dk0, dk1, 1.0f);
-        stage_tile(sB, wave * 32, lane, dv0, dv1, 1.0f);
+        stage_tile(sC, wave * 32, lane, dv0, dv1, 1.0f);
         if (!(ablate & 4)) {
             flush_tile(sA, wave * 32, lane, dbase + C, rs, L);
-            flush_tile(sB, wave * 32, lane, dbase + 2 * C, rs, L);
+            flush_tile(sC, wave * 32, lane, dbase + 2 * C, rs, L);
         }
+    }
+}
+
+// Causal variant (text tower).  With the causal mask the work of a wave is triangular: query block w sees w + 1 key blocks
+// (phase A), key block w is seen by nwaves - w query blocks (phase B) -- balanced in total, but a barrier between the phases
+// makes every wave wait for the longest of each.  Here Q, K, V and dO all stay resident and the outputs leave through a fifth
+// buffer (only the wave's own rows of it), so there is no barrier after the one that publishes the images and a wave runs its
+// phase A and phase B back to back.  5 images are affordable exactly where this matters: at L = 77 the register budget, not LDS,
+// caps the text tower at two workgroups per CU.
+template <int MAXT, int WPE>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_causal_kernel(
+    const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout, const float* __restrict__ lse,
+    bf16* __restrict__ dqkv, int L, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int LP = nwaves * 32;
+    const int b = blockIdx.x / H, hd = blockIdx.x % H;
+    const int C = H * 64;
+    const size_t rs = (size_t)3 * C;
+    const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
+    const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
+    const bf16* obase = out + (size_t)b * L * C + hd * 64;
+    char* sQ = smem;
+    char* sK = smem + LP * 128;
+    char* sV = smem + 2 * LP * 128;
+    char* sdO = smem + 3 * LP * 128;
+    char* sT = smem + 4 * LP * 128;  // transposing buffer of dQ, dK, dV (a wave only touches its own 32 rows)
+    float* sLse = (float*)(smem + 5 * LP * 128);
+    float* sDelta = sLse + LP;
+    const int lr = lane & 31, lh = lane >> 5;
+    const float sc = scale * LOG2E;
+    stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
+    stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
+    stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
+    stage_head(dobase, (size_t)C, L, LP, sdO, wave, nwaves, lane);
+    const int qb = wave, query = qb * 32 + lr;
+    const int qrow = query < L ? query : L - 1;
+    bf16x8 of[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) of[s] = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
+    const float lse_q = lse[((size_t)b * H + hd) * L + qrow] * LOG2E;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
+
+    // every wave first publishes lse / delta of its query block (phase B of OTHER waves reads them) ...
+    bf16x8 qf[4], dof[4];
+    float delta_q = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = frag_rows(sQ, query, s, lane);
+        dof[s] = frag_rows(sdO, query, s, lane);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[s][e]);
+    }
+    delta_q += __shfl_xor(delta_q, 32, 64);
+    if (lh == 0) {
+        sLse[query] = lse_q;
+        sDelta[query] = delta_q;
+    }
+    __syncthreads();
+
+    // ---- phase A: dQ for query block `wave` (keys 0 .. query block) ----
+    {
+        f32x16 dq0 = zero16(), dq1 = zero16();
+        for (int kb = 0; kb <= qb; ++kb) {
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = mfma32(frag_rows(sK, kb * 32 + lr, s, lane), qf[s], st);
+                dp = mfma32(frag_rows(sV, kb * 32 + lr, s, lane), dof[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + mfma32_row(r, lane);
+                const bool ok = key < L && query < L && key <= query;
+                const float p = ok ? exp2f(st[r] * sc - lse_q) : 0.f;
+                st[r] = p * (dp[r] - delta_q) * scale;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 dsf = pack8(st, t);
+                dq0 = mfma32(frag_cols(sK, kb * 32, t, 0, lane), dsf, dq0);
+                dq1 = mfma32(frag_cols(sK, kb * 32, t, 1, lane), dsf, dq1);
+            }
+        }
+        stage_tile(sT, wave * 32, lane, dq0, dq1, 1.0f);
+        flush_tile(sT, wave * 32, lane, dbase, rs, L);
+    }
+
+    // ---- phase B: dK, dV for key block `wave` (queries from the key block on) ----
+    {
+        const int kb = wave;
+        const int key = kb * 32 + lr;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = frag_rows(sK, key, s, lane);
+            vf[s] = frag_rows(sV, key, s, lane);
+        }
+        f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+        for (int q2 = kb; q2 < nwaves; ++q2) {
+            f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = mfma32(frag_rows(sQ, q2 * 32 + lr, s, lane), kf[s], st);
+                dp = mfma32(frag_rows(sdO, q2 * 32 + lr, s, lane), vf[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = q2 * 32 + mfma32_row(r, lane);
+                const bool ok = key < L && qq < L && key <= qq;
+                const float p = ok ? exp2f(st[r] * sc - sLse[qq]) : 0.f;
+                dp[r] = p * (dp[r] - sDelta[qq]) * scale;
+                st[r] = p;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 pf = pack8(st, t), dsf = pack8(dp, t);
+                dv0 = mfma32(frag_cols(sdO, q2 * 32, t, 0, lane), pf, dv0);
+                dv1 = mfma32(frag_cols(sdO, q2 * 32, t, 1, lane), pf, dv1);
+                dk0 = mfma32(frag_cols(sQ, q2 * 32, t, 0, lane), dsf, dk0);
+                dk1 = mfma32(frag_cols(sQ, q2 * 32, t, 1, lane), dsf, dk1);
+            }
+        }
+        // the wave's rows of the transposing buffer: dQ's reads are complete (flush_tile consumed them), dK then dV follow
+        stage_tile(sT, wave * 32, lane, dk0, dk1, 1.0f);
+        flush_tile(sT, wave * 32, lane, dbase + C, rs, L);
+        stage_tile(sT, wave * 32, lane, dv0, dv1, 1.0f);
+        flush_tile(sT, wave * 32, lane, dbase + 2 * C, rs, L);
     }
 }
 
@@ -369,6 +499,18 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
     int lds = 3 * nw * 32 * 128 + 2 * nw * 32 * 4;
     OCN_CHECK_ARG(lds <= 160 * 1024, "ocn_attn_bwd: L=%d needs %d bytes of LDS (> 160 KiB)", L, lds);
     if (g_ocn_tuning[5] > 0 && lds + g_ocn_tuning[5] * 1024 <= 160 * 1024) lds += g_ocn_tuning[5] * 1024;  // developer knob: lower the occupancy
+    const int lds5 = 5 * nw * 32 * 128 + 2 * nw * 32 * 4;
+    if (causal && nw >= 2 && nw <= 3 && g_ocn_tuning[6] != 1 && g_ocn_tuning[1] == 0) {  // developer knob 6 = 1: use the generic kernel
+        static bool cattr_set = false;
+        if (!cattr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_causal_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            cattr_set = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_causal_kernel<256, 2>), dim3(B * H), dim3(nw * 64), lds5, (hipStream_t)stream, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, scale);
+        OCN_CHECK_LAUNCH("ocn_attn_bwd");
+        return OCN_OK;
+    }
     const bool three = g_ocn_tuning[2] == 3;  // developer knob 2 = 3: the 168-VGPR build (3 waves per SIMD, ~22 spilled registers; measured no faster: profiles/r01_attn_bwd_two_pass.txt)
     if (nw <= 4 && three) {
         static bool attr_set = false;

@@ -67,7 +67,7 @@ OCN_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long row0, int rows_t
     return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + row0 * ld * esz), 0, (int)bytes, 0x00020000);
 }
 
-template <int EPI>
+template <int EPI, int AUX = 0>
 OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg,
                        long long* dbg = nullptr) {
     // Lane constants are laundered through an empty asm once per tile: otherwise hipcc hoists ~40 VGPRs of epilogue
@@ -134,7 +134,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     for (int it = 0; it < 4; ++it) {
                         const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
                         const unsigned off = (unsigned)(row * a.ldc) * 2u + col_off;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, AUX);
                     }
                 }
     } else {
@@ -180,14 +180,14 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             for (int it = 0; it < 4; ++it) {
                 const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
                 if (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, AUX);
                 } else if (EPI == OCN_EPI_DGELU) {
                     f32x4 dg = ex[it];
                     if (!(a.ablate & 1)) dg = (f32x4){dgelu_f(dg[0]), dgelu_f(dg[1]), dgelu_f(dg[2]), dgelu_f(dg[3])};  // (developer knob: skip the VALU work)
                     const bf16x4 o4 = {f2bf(v[0] * dg[0]), f2bf(v[1] * dg[1]), f2bf(v[2] * dg[2]), f2bf(v[3] * dg[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, AUX);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, AUX);
                 }
             }
         }
@@ -196,7 +196,8 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 
 // DBG = developer build of the same kernel that logs a per-tile timeline into a.aux (tools/gemm_trace.py; plain bf16
 // epilogue only); the production instantiation folds it away.
-template <int EPI, bool DBG>
+// AUX = cache-policy bits of the epilogue's stores (0 = default write-back, 2 = non-temporal: developer experiment)
+template <int EPI, bool DBG, int AUX = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         STAMP(3)
         int m0, n0;
         tile_origin(i, m0, n0);
-        epilogue5<EPI>(a, acc, m0, n0, wm, wn, lane, stg, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
+        epilogue5<EPI, AUX>(a, acc, m0, n0, wm, wn, lane, stg, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
         STAMP(4)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released
@@ -509,6 +510,16 @@ int launch5(GemmNtArgs a, hipStream_t st) {
             dbg_attr_set = true;
         }
         hipLaunchKernelGGL((gemm_nt5_kernel<EPI, true>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+        OCN_CHECK_LAUNCH("ocn_gemm_nt");
+        return OCN_OK;
+    }
+    if (a.ablate & 2) {  // developer experiment: non-temporal epilogue stores
+        static bool nt_attr_set = false;
+        if (!nt_attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            nt_attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, 2>), dim3(grid), dim3(512), LDS_BYTES, st, a);
         OCN_CHECK_LAUNCH("ocn_gemm_nt");
         return OCN_OK;
     }

@@ -89,6 +89,12 @@ def attn_wpe_sweep():
             ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
             row.append(f"wpe {wpe}: {ms:.3f} ms{'' if torch.equal(got, ref) else ' (MISMATCH)'}")
         _lib.call("ocn_set_tuning", 2, 0)
+        if causal:  # barrier-free 5-image causal kernel (default) against the generic one
+            _lib.call("ocn_set_tuning", 6, 1)
+            got = ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125)
+            ms = timeit(lambda: ops.attn_bwd(qkv, out, do, lse, B, L, H, causal, 0.125))
+            _lib.call("ocn_set_tuning", 6, 0)
+            row.append(f"generic kernel: {ms:.3f} ms (max |diff| vs causal kernel {float((got.float() - ref.float()).abs().max()):.2e})")
         print(f"attn bwd {name} L={L}: " + " | ".join(row), flush=True)
         row = []
         for extra_kb in (0, 8, 20, 45):  # fewer resident workgroups per CU: does the arithmetic-only time scale with occupancy?
@@ -117,6 +123,30 @@ def tn_sweep():
         _lib.call("ocn_set_tuning", 4, 0)
         print(f"tn {name:9s} dW[{N},{K}]: " + " | ".join(row), flush=True)
         del a, b
+
+
+def ntstore_sweep():
+    """epilogue stores with the non-temporal cache policy (developer knob bit 2 of the ablation mask)"""
+    cases = [("img fc", Mi, 3072, 768, [0, 1, 3]), ("img out", Mi, 768, 768, [2]), ("img proj", Mi, 768, 3072, [2]),
+             ("txt fc", Mt, 2048, 512, [1, 3]), ("txt out", Mt, 512, 512, [2])]
+    for name, M, N, K, epis in cases:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, device=dev)
+        for epi in epis:
+            f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
+            out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+            resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
+            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            row = []
+            for mask in (0, 2, 0, 2):
+                _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
+                ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
+                row.append(f"{'nt' if mask else 'wb'} {2.0 * M * N * K / ms / 1e9:5.0f}")
+            print(f"{name:9s} epi {epi} (TF/s): " + " | ".join(row), flush=True)
+            del out, resid, aux
+        del a, b
+    _lib.call("ocn_set_gemm_variant", 0)
 
 
 def stagger_sweep():
@@ -149,6 +179,8 @@ if __name__ == "__main__":
         attn_sweep()
     if what in ("all", "nt"):
         nt_sweep()
+    if what in ("all", "ntstore"):
+        ntstore_sweep()
     if what in ("all", "stagger"):
         stagger_sweep()
     if what in ("all", "attnw"):
