@@ -87,12 +87,20 @@ int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float
 /* ---- attention core (transformer.py:199-244: head split + F.scaled_dot_product_attention) ------
  * qkv bf16 [B*L, 3*H*64] (q | k | v column blocks, heads contiguous inside each: the layout F.linear with
  * in_proj_weight produces, transformer.py:169); out bf16 [B*L, H*64]; lse fp32 [B*H*L] (natural log).
- * head_dim is 64; L <= 128.  causal != 0 applies the text tower's upper-triangular -inf mask
+ * head_dim is 64; L <= 320.  causal != 0 applies the text tower's upper-triangular -inf mask
  * (transformer.py:1716-1722) as a predicate. */
 int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int causal, float scale,
                  ocn_stream_t stream);
 int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L, int H,
                  int causal, float scale, ocn_stream_t stream);
+/* The same with an explicit head_dim (64, 80, 96 or 128; qkv [B*L, 3*H*head_dim]): head_dim 64 with L <= 320 runs the
+ * kernels above, everything else (ViT-H-14: head_dim 80, 257 tokens) the K/V-resident query-tiled kernels of
+ * csrc/attention_generic.hip, which need 2 * roundup(L,32) * roundup(head_dim,32) * 2 bytes <= 160 KiB of LDS.  The backward's
+ * workspace `delta_ws` is fp32 [B*H*L] (sum_d dO*O, exchanged between its two launches; may be NULL on the head_dim-64 path). */
+int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, int causal, float scale,
+                    ocn_stream_t stream);
+int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int L,
+                    int H, int head_dim, int causal, float scale, ocn_stream_t stream);
 
 /* ---- image tower embedding (transformer.py:793-808) -------------------------------------------
  * patchify: image [B,3,H,W] (fp32, or bf16 when image_is_bf16) -> patches bf16 [B*gh*gw, Kpad], column order

@@ -25,6 +25,8 @@ SIGNATURES = {
     "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_fwd_hd": [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_bwd_hd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "ocn_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "ocn_patchify_u8": [_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _p, _i, _i, _i, _i, _i, _p],
     "ocn_embed_assemble_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],

@@ -33,6 +33,12 @@ _MODEL_CONFIGS = {
         "vision_cfg": {"image_size": 64, "layers": 2, "width": 128, "patch_size": 32},
         "text_cfg": {"context_length": 16, "vocab_size": 512, "width": 128, "heads": 2, "layers": 2},
     },
+    # ViT-H-14's shape class in miniature: image head_dim 80 (head_width 80), patch 14, odd token count (26), text head_dim 64
+    "hd80-test": {
+        "embed_dim": 96,
+        "vision_cfg": {"image_size": 70, "layers": 2, "width": 160, "head_width": 80, "patch_size": 14},
+        "text_cfg": {"context_length": 77, "vocab_size": 1024, "width": 128, "heads": 2, "layers": 2},
+    },
     "small-test": {
         "embed_dim": 128,
         "vision_cfg": {"image_size": 96, "layers": 2, "width": 256, "patch_size": 16},

@@ -540,3 +540,34 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
     OCN_CHECK_LAUNCH("ocn_attn_bwd");
     return OCN_OK;
 }
+
+// ---- explicit head_dim: dispatch between the specialised (head_dim 64, head resident) and the generic kernels ---------------
+int ocn_launch_attn_generic_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int D, int causal, float scale, hipStream_t st);
+int ocn_launch_attn_generic_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int B,
+                                int L, int H, int D, int causal, float scale, hipStream_t st);
+
+extern "C" int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, int causal, float scale,
+                               ocn_stream_t stream) {
+    if (head_dim == 64 && L <= 320 && g_ocn_tuning[7] != 1) return ocn_attn_fwd(qkv, out, lse, B, L, H, causal, scale, stream);  // knob 7 = 1: force the generic path
+    OCN_CHECK_ARG(qkv && out && lse && B > 0 && L > 0 && H > 0, "ocn_attn_fwd_hd: bad arguments");
+    const int rc = ocn_launch_attn_generic_fwd(qkv, out, lse, B, L, H, head_dim, causal, scale, (hipStream_t)stream);
+    if (rc == 1) {
+        ocn_set_error("ocn_attn_fwd_hd: head_dim=%d, L=%d unsupported (head_dim in {64,80,96,128}; K and V of a head must fit 160 KiB of LDS)", head_dim, L);
+        return OCN_ERR_UNSUPPORTED;
+    }
+    OCN_CHECK_LAUNCH("ocn_attn_fwd_hd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B,
+                               int L, int H, int head_dim, int causal, float scale, ocn_stream_t stream) {
+    if (head_dim == 64 && L <= 320 && g_ocn_tuning[7] != 1) return ocn_attn_bwd(qkv, out, dout, lse, dqkv, B, L, H, causal, scale, stream);
+    OCN_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "ocn_attn_bwd_hd: bad arguments");
+    const int rc = ocn_launch_attn_generic_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, L, H, head_dim, causal, scale, (hipStream_t)stream);
+    if (rc == 1) {
+        ocn_set_error("ocn_attn_bwd_hd: head_dim=%d, L=%d unsupported (head_dim in {64,80,96,128}; Q and dO of a head must fit 160 KiB of LDS)", head_dim, L);
+        return OCN_ERR_UNSUPPORTED;
+    }
+    OCN_CHECK_LAUNCH("ocn_attn_bwd_hd");
+    return OCN_OK;
+}

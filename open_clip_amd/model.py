@@ -150,7 +150,8 @@ def _block_forward(x, p, cache, B, L, heads, causal):
     M, C = x.shape
     h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
     qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
-    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, 64 ** -0.5)
+    hd = C // heads
+    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd)
     xmid = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, cache.get(wo, "n"), ops.empty((M, C), F32, x), bias=bo, resid=x)
     h2, _, mean2, rstd2 = ops.layernorm_fwd(xmid, ln2w, ln2b)
     Fd = wfc.shape[0]
@@ -207,7 +208,7 @@ class _BlockFn(torch.autograd.Function):
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev) as side:
             side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
-            dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, 64 ** -0.5)
+            dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev) as side:
             side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo)
@@ -484,8 +485,9 @@ class NativeCLIP(nn.Module):
         self.output_dict = output_dict
         self.embed_dim = embed_dim
         head_width = v.get("head_width", 64)
-        if head_width != 64 or t["width"] // t["heads"] != 64:
-            raise NotImplementedError("the native attention kernels support head_dim 64 only (ViT-B/L towers)")
+        for hd in (head_width, t["width"] // t["heads"]):
+            if hd not in (64, 80, 96, 128):
+                raise NotImplementedError(f"the native attention kernels support head_dim 64 / 80 / 96 / 128 (got {hd})")
         self.visual = VisionTransformer(v["image_size"], v["patch_size"], v["width"], v["layers"], v["width"] // head_width,
                                         v.get("mlp_ratio", 4.0), embed_dim)
         tw = t["width"]

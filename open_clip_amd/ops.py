@@ -112,21 +112,22 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_b
 
 
 # ---- attention -------------------------------------------------------------------------------------------
-def attn_fwd(qkv, B, L, H, causal, scale):
-    C = H * 64
+def attn_fwd(qkv, B, L, H, causal, scale, head_dim=64):
+    C = H * head_dim
     if qkv.shape != (B * L, 3 * C):
-        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(B * L, 3 * C)} (head_dim must be 64)")
+        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(B * L, 3 * C)} (H={H}, head_dim={head_dim})")
     out = empty((B * L, C), BF16, qkv)
     lse = empty((B * H * L,), F32, qkv)
-    _lib.call("ocn_attn_fwd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), B, L, H, int(causal),
+    _lib.call("ocn_attn_fwd_hd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), B, L, H, head_dim, int(causal),
               float(scale), _stream())
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale):
+def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale, head_dim=64):
     dqkv = empty(qkv.shape, BF16, qkv)
-    _lib.call("ocn_attn_bwd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
-              _chk(dqkv, BF16, "dqkv"), B, L, H, int(causal), float(scale), _stream())
+    delta = empty((B * H * L,), F32, qkv)  # workspace of the generic path (exchanged between its two launches)
+    _lib.call("ocn_attn_bwd_hd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
+              _chk(dqkv, BF16, "dqkv"), _chk(delta, F32, "delta"), B, L, H, head_dim, int(causal), float(scale), _stream())
     return dqkv
 
 

@@ -234,10 +234,10 @@ def test_layernorm(dev, M, C):
 
 
 # ---------------------------------------------------------------------------------------------------
-def _attn_ref(qkv, B, L, H, causal):
-    C = H * 64
-    q, k, v = qkv.float().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
-    s = (q @ k.transpose(-1, -2)) * 0.125
+def _attn_ref(qkv, B, L, H, causal, D=64):
+    C = H * D
+    q, k, v = qkv.float().reshape(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * D ** -0.5
     if causal:
         s = s + torch.full((L, L), float("-inf"), device=qkv.device).triu_(1)
     p = torch.softmax(s, dim=-1)
@@ -264,6 +264,42 @@ def test_attention(dev, B, L, H, causal):
     check(tag + " dqkv", dqkv, x.grad, rel=1.5e-2)          # P, dS rounded to bf16; delta from bf16 O
     for i, nm in enumerate("qkv"):
         check(tag + f" d{nm}", dqkv[:, i * C:(i + 1) * C], x.grad[:, i * C:(i + 1) * C], rel=2e-2)
+
+
+@pytest.mark.parametrize("B,L,H,D,causal,force", [(2, 257, 2, 80, False, False), (3, 50, 3, 80, False, False), (2, 77, 2, 80, True, False),
+                                                 (1, 257, 1, 128, False, False), (2, 40, 2, 96, True, False), (1, 400, 2, 64, False, False),
+                                                 (2, 400, 1, 64, True, False), (3, 50, 2, 64, False, True), (2, 77, 3, 64, True, True), (4, 7, 2, 80, True, False)])
+def test_attention_generic_head_dims(dev, B, L, H, D, causal, force):
+    """K/V-resident query-tiled kernels (csrc/attention_generic.hip): head_dim 80 / 96 / 128 (ViT-H-14: 80 x 257 tokens), head_dim
+    64 beyond 320 tokens, and -- forced through developer knob 7 -- the head_dim-64 shapes of the specialised kernels, which must
+    agree with them.  Same tolerances as test_attention."""
+    from open_clip_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * L + H + D)
+    C = H * D
+    scale = D ** -0.5
+    qkv = bf(torch.randn(B * L, 3 * C, generator=g) * 1.5).to(dev)
+    dout = bf(torch.randn(B * L, C, generator=g)).to(dev)
+    if force:
+        out0, lse0 = ops.attn_fwd(qkv, B, L, H, causal, scale, D)
+        d0 = ops.attn_bwd(qkv, out0, dout, lse0, B, L, H, causal, scale, D)
+        _lib.call("ocn_set_tuning", 7, 1)
+    try:
+        out, lse = ops.attn_fwd(qkv, B, L, H, causal, scale, D)
+        dqkv = ops.attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale, D)
+    finally:
+        _lib.call("ocn_set_tuning", 7, 0)
+    x = qkv.float().requires_grad_(True)
+    ref, ref_lse = _attn_ref(x, B, L, H, causal, D)
+    tag = f"attn_generic[B{B} L{L} H{H} D{D} c{int(causal)}]"
+    check(tag + " out", out, ref.detach(), rel=6e-3)
+    check(tag + " lse", lse, ref_lse.detach(), rel=1e-5)
+    ref.backward(dout.float())
+    check(tag + " dqkv", dqkv, x.grad, rel=1.5e-2)
+    for i, nm in enumerate("qkv"):
+        check(tag + f" d{nm}", dqkv[:, i * C:(i + 1) * C], x.grad[:, i * C:(i + 1) * C], rel=2e-2)
+    if force:
+        check(tag + " out vs specialised kernel", out, out0, rel=2e-3)
+        check(tag + " dqkv vs specialised kernel", dqkv, d0, rel=6e-3)
 
 
 # ---------------------------------------------------------------------------------------------------

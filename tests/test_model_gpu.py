@@ -232,3 +232,44 @@ def test_state_carried_between_steps_is_not_stale():
     for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         rel = float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-30))
         assert rel < 1e-4, (k, rel)
+
+
+@pytest.mark.parametrize("siglip", [True, False])
+def test_head_dim_80_tower_against_cpu_oracle(siglip):
+    """BASELINE config 5's shape class (ViT-H-14 + SigLIP: image head_dim 80, patch 14, sigmoid pairwise loss with logit_bias) in
+    miniature: the image tower runs the generic attention kernels, the text tower the specialised ones."""
+    from oracle import clip_oracle as O
+    cfg = get_model_config("hd80-test")
+    state = init_state_dict(cfg, seed=9, perturb=True, siglip=siglip)
+    batch = synthetic_batch(cfg, 6, seed=23)
+    outs, grads = O.train_forward_backward(batch["image"], batch["text"], state, cfg, siglip=siglip)
+    model = _build(cfg, state, siglip)
+    out, loss = _step(model, batch, siglip)
+    fi = float((out["image_features"].float().cpu() - outs["image_features"]).abs().max())
+    ft = float((out["text_features"].float().cpu() - outs["text_features"]).abs().max())
+    _report(f"oracle[hd80-test,siglip{int(siglip)}]: feat max_abs {fi:.3e}/{ft:.3e} loss {float(loss):.6f} vs {float(outs['loss']):.6f}")
+    assert fi <= FEAT_TOL and ft <= FEAT_TOL
+    assert abs(float(loss) - float(outs["loss"])) <= LOSS_TOL
+    gmax = max(float(v.norm()) for v in grads.values())
+    for k, p in model.named_parameters():
+        ref = grads[k]
+        rel = float((p.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        tol = GRAD_TOL if float(ref.norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        assert rel <= tol, (k, rel)
+
+
+def test_vith14_siglip_full_size_step_runs():
+    """BASELINE config 5 at full model size (ViT-H-14: 32 image blocks of width 1280 / head_dim 80 / 257 tokens, 24 text blocks of
+    width 1024; SigLIP loss): one grad-checkpointed step at a small batch -- finite loss, unit-norm features, a finite gradient
+    on every parameter.  (Numerical parity of this shape class: test_head_dim_80_tower_against_cpu_oracle.)"""
+    cfg = get_model_config("ViT-H-14")
+    model = _build(cfg, init_state_dict(cfg, seed=0, siglip=True), siglip=True)
+    model.set_grad_checkpointing(True)
+    batch = synthetic_batch(cfg, 4, seed=3)
+    out, loss = _step(model, batch, siglip=True)
+    assert torch.isfinite(loss.detach())
+    for k in ("image_features", "text_features"):
+        f = out[k].float()
+        assert torch.isfinite(f).all() and float((f.norm(dim=-1) - 1).abs().max()) < 1e-3
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
