@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
-FWD_GFLOP_PER_PAIR = {"ViT-B-32": 14.78, "ViT-L-14": 175.33}  # docs/model_profile.csv (reference)
+FWD_GFLOP_PER_PAIR = {"ViT-B-32": 14.78, "ViT-L-14": 175.33, "ViT-H-14": 381.68}  # docs/model_profile.csv (reference)
 
 
 def parse():
@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
     ap.add_argument("--naive-global-loss", action="store_true", help="N>1: every rank evaluates the full N x N logits (the reference's "
                     "redundant form) instead of its own rows (same loss and gradients; tests/test_dist_loss_gloo.py, test_ddp_gpu.py)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="developer: value for ocn_set_gemm_variant (kernel choice / ablation knobs)")
@@ -143,15 +144,20 @@ def main():
         _lib.call("ocn_set_gemm_variant", args.gemm_variant)
     cfg = get_model_config(args.model)
     torch.manual_seed(0)
-    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True)
-    model.load_state_dict(init_state_dict(cfg, seed=0))
+    extra = dict(init_logit_scale=math.log(10), init_logit_bias=-10.0) if args.siglip else {}  # main.py:259-261
+    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True, **extra)
+    model.load_state_dict(init_state_dict(cfg, seed=0, siglip=args.siglip))
     model = model.to(dev).train()
     if args.grad_checkpointing:
         model.set_grad_checkpointing(True)
     B = args.local_batch
     batch = synthetic_batch(cfg, B, seed=1234, rank=rank, device=dev)
-    loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
-                             row_sharded=(world > 1 and not args.naive_global_loss))
+    if args.siglip:
+        from open_clip_amd.loss import NativeSigLipLoss
+        loss_fn = NativeSigLipLoss(rank=rank, world_size=world)
+    else:
+        loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
+                                 row_sharded=(world > 1 and not args.naive_global_loss))
     opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
     if world > 1:
@@ -203,7 +209,7 @@ def main():
             "metric": "image-text pairs/sec (whole node), ViT-B-32 gbs=32768 at 1/2/4/8 GPUs", "value": round(value, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} CLIPTask-equivalent train step (fwd+ClipLoss+bwd+AdamW+clamp), amp_bf16 policy, "
+            "config": {"workload": f"{args.model} {'SigLIPTask' if args.siglip else 'CLIPTask'}-equivalent train step (fwd+{'SigLipLoss' if args.siglip else 'ClipLoss'}+bwd+AdamW+clamp), amp_bf16 policy, "
                                    f"local_bs={B}, global_bs={B * world}, "
                                    + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
                                       if world > 1 else "world_size 1 (no all-gather)"),
@@ -224,7 +230,10 @@ def main():
                                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "launches": nt["launches"], "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4),
                                 "algorithmic_tflop_per_launch_avg": round(nt["tflop"] / max(nt["launches"], 1), 4),
                                 "gemm_tn_kernel": {"achieved": round(tn["tflops"], 1), "frac": round(tn["tflops"] / PEAK_BF16_TFLOPS, 4),
-                                                   "launches": tn["launches"], "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4)},
+                                                   "launches": tn["launches"], "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4),
+                                                   "note": "wgrad launches run on a side stream UNDER the LayerNorm / attention backward kernels of "
+                                                           "their block (model.py::_Paired), so these events time a co-scheduled kernel; alone it "
+                                                           "runs at ~1.2 PFLOP/s (profiles/r01_gemm_shapes.txt, OCN_WGRAD_STREAM=0)"},
                                 "event_timed_steps": timed_steps,
                                 "gemm_share_of_step": round((nt["ms"] + tn["ms"]) / (elapsed * 1e3 * timed_steps / args.steps), 3)}
         if world == 1 and not args.no_cpu_baseline:

@@ -66,6 +66,8 @@ def load():
                 f"{LIB_PATH} not found: the HIP extension is required (no fallback path). "
                 "Build it with `python -m open_clip_amd.build` (needs hipcc, cross-compiles for gfx950)."
             )
+        import torch  # noqa: F401  -- BEFORE the CDLL: the library must bind to the HIP runtime torch has loaded (its bundled
+        #                 libamdhip64), not pull a second copy from /opt/rocm that knows no device ("no ROCm-capable device")
         lib = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
