@@ -32,9 +32,9 @@ enum ocn_status { OCN_OK = 0, OCN_ERR_INVALID = -1, OCN_ERR_LAUNCH = -2, OCN_ERR
 /* epilogues of ocn_gemm_nt */
 enum ocn_epilogue {
     OCN_EPI_BF16 = 0,           /* out_bf16 = alpha*acc + bias                                            */
-    OCN_EPI_BIAS_GELU = 1,      /* aux_bf16 = acc + bias (pre-activation, saved); out_bf16 = gelu(acc+bias) */
+    OCN_EPI_BIAS_GELU = 1,      /* out_bf16 = gelu(acc+bias); aux_bf16 = gelu'(acc+bias) (saved for EPI 3)  */
     OCN_EPI_BIAS_RESID_F32 = 2, /* out_f32 = resid_f32 + acc + bias                                       */
-    OCN_EPI_DGELU = 3,          /* out_bf16 = acc * gelu'(aux_bf16)                                       */
+    OCN_EPI_DGELU = 3,          /* out_bf16 = acc * aux_bf16   (aux = the gelu' saved by EPI 1)            */
     OCN_EPI_F32 = 4             /* out_f32 = alpha*acc + bias                                             */
 };
 

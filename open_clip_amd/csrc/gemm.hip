@@ -51,17 +51,24 @@ OCN_DEV void epilogue_store4(const GemmNtArgs& a, int gm, int gn, f32x4 v) {
         bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_BIAS_GELU) {
-        bf16x4 p4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        f32x4 gv, dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g1, d1;
+            gelu_both(v[e], g1, d1);
+            gv[e] = g1;
+            dv[e] = d1;
+        }
+        bf16x4 p4 = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])};  // aux = gelu'(pre-activation)
         *(bf16x4*)(a.aux + o) = p4;
-        bf16x4 o4 = {f2bf(gelu_f(v[0])), f2bf(gelu_f(v[1])), f2bf(gelu_f(v[2])), f2bf(gelu_f(v[3]))};
+        bf16x4 o4 = {f2bf(gv[0]), f2bf(gv[1]), f2bf(gv[2]), f2bf(gv[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
         const f32x4 r = *(const f32x4*)(a.resid + o);
         *(f32x4*)((float*)a.out + o) = v + r;
     } else if (EPI == OCN_EPI_DGELU) {
         const bf16x4 p4 = *(const bf16x4*)(a.aux + o);
-        bf16x4 o4 = {f2bf(v[0] * dgelu_f(bf2f(p4[0]))), f2bf(v[1] * dgelu_f(bf2f(p4[1]))),
-                     f2bf(v[2] * dgelu_f(bf2f(p4[2]))), f2bf(v[3] * dgelu_f(bf2f(p4[3])))};
+        bf16x4 o4 = {f2bf(v[0] * bf2f(p4[0])), f2bf(v[1] * bf2f(p4[1])), f2bf(v[2] * bf2f(p4[2])), f2bf(v[3] * bf2f(p4[3]))};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else {  // OCN_EPI_F32
         *(f32x4*)((float*)a.out + o) = v;
@@ -75,12 +82,14 @@ OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
     if (EPI == OCN_EPI_BF16) {
         ((bf16*)a.out)[o] = f2bf(v * a.alpha + b);
     } else if (EPI == OCN_EPI_BIAS_GELU) {
-        a.aux[o] = f2bf(v + b);
-        ((bf16*)a.out)[o] = f2bf(gelu_f(v + b));
+        float g1, d1;
+        gelu_both(v + b, g1, d1);
+        a.aux[o] = f2bf(d1);
+        ((bf16*)a.out)[o] = f2bf(g1);
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
         ((float*)a.out)[o] = v + b + a.resid[o];
     } else if (EPI == OCN_EPI_DGELU) {
-        ((bf16*)a.out)[o] = f2bf((v + b) * dgelu_f(bf2f(a.aux[o])));
+        ((bf16*)a.out)[o] = f2bf((v + b) * bf2f(a.aux[o]));
     } else {
         ((float*)a.out)[o] = v * a.alpha + b;
     }
@@ -231,15 +240,22 @@ OCN_DEV void epi_apply_store(const GemmNtArgs& a, int gm, int gn, f32x4 v, f32x4
         bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_BIAS_GELU) {
-        bf16x4 p4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        f32x4 gv, dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g1, d1;
+            gelu_both(v[e], g1, d1);
+            gv[e] = g1;
+            dv[e] = d1;
+        }
+        bf16x4 p4 = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])};  // aux = gelu'(pre-activation)
         *(bf16x4*)(a.aux + o) = p4;
-        bf16x4 o4 = {f2bf(gelu_f(v[0])), f2bf(gelu_f(v[1])), f2bf(gelu_f(v[2])), f2bf(gelu_f(v[3]))};
+        bf16x4 o4 = {f2bf(gv[0]), f2bf(gv[1]), f2bf(gv[2]), f2bf(gv[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
         *(f32x4*)((float*)a.out + o) = v + extra;
     } else if (EPI == OCN_EPI_DGELU) {
-        bf16x4 o4 = {f2bf(v[0] * dgelu_f(extra[0])), f2bf(v[1] * dgelu_f(extra[1])), f2bf(v[2] * dgelu_f(extra[2])),
-                     f2bf(v[3] * dgelu_f(extra[3]))};
+        bf16x4 o4 = {f2bf(v[0] * extra[0]), f2bf(v[1] * extra[1]), f2bf(v[2] * extra[2]), f2bf(v[3] * extra[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else {
         *(f32x4*)((float*)a.out + o) = v;

@@ -112,21 +112,40 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                // GELU: gelu(v) AND gelu'(v) come out of one evaluation of the shared erf / exp parts; the derivative is what
+                // is saved for the backward (aux), whose epilogue is then a plain multiply (EPI_DGELU below)
+                bf16x4 pk[ROUNDS][2][4];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
+                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else v = v + bv[hb][g];
+                        if (EPI == OCN_EPI_BIAS_GELU) {
+                            f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
+                            if (!(a.ablate & 1)) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float g1, d1;
+                                    gelu_both(v[e], g1, d1);
+                                    gv[e] = g1;
+                                    dv[e] = d1;
+                                }
+                            }
+                            pk[0][hb][g] = (bf16x4){f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])};
+                            pk[ROUNDS - 1][hb][g] = (bf16x4){f2bf(gv[0]), f2bf(gv[1]), f2bf(gv[2]), f2bf(gv[3])};
+                        } else {
+                            pk[0][hb][g] = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                        }
+                    }
 #pragma unroll
                 for (int rnd = 0; rnd < ROUNDS; ++rnd) {
                     if (dbg && ha == 1 && s == 0 && rnd == 0) dbg[6] = wall_clock64();
 #pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
+                    for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
-                            if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else v = v + bv[hb][g];
-                            if (EPI == OCN_EPI_BIAS_GELU && rnd == 1 && !(a.ablate & 1)) v = (f32x4){gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
-                            const bf16x4 pk = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                            lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk);
-                        }
-                    }
+                        for (int g = 0; g < 4; ++g) lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk[rnd][hb][g]);
                     const bool to_aux = (EPI == OCN_EPI_BIAS_GELU && rnd == 0);
                     bf16x8 d[4];
                     lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
@@ -137,6 +156,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, AUX);
                     }
                 }
+            }
     } else {
         // 32x32 fp32 blocks (128-byte rows).  The epilogue operand of block k+1 (residual rows / saved pre-activation)
         // is fetched BEFORE block k's stores are issued, so waiting for it never drains the stores.
@@ -182,8 +202,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                 if (EPI == OCN_EPI_BIAS_RESID_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, AUX);
                 } else if (EPI == OCN_EPI_DGELU) {
-                    f32x4 dg = ex[it];
-                    if (!(a.ablate & 1)) dg = (f32x4){dgelu_f(dg[0]), dgelu_f(dg[1]), dgelu_f(dg[2]), dgelu_f(dg[3])};  // (developer knob: skip the VALU work)
+                    const f32x4 dg = ex[it];  // gelu'(pre-activation), saved by the forward epilogue
                     const bf16x4 o4 = {f2bf(v[0] * dg[0]), f2bf(v[1] * dg[1]), f2bf(v[2] * dg[2]), f2bf(v[3] * dg[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, AUX);
                 } else {
@@ -441,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         int m0, n0;
         tile_origin(i, m0, n0);
         epilogue5<EPI, AUX>(a, acc, m0, n0, wm, wn, lane, stg, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
+        if (a.ablate & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // developer knob: let the tile's stores drain before the next main loop
         STAMP(4)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released

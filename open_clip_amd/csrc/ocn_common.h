@@ -86,6 +86,13 @@ OCN_DEV float gelu_f(float x) {
     gelu_parts(x, cdf, e);
     return x * cdf;
 }
+// gelu(x) and gelu'(x) from ONE evaluation of the shared parts (forward GELU epilogue: the derivative is what gets saved)
+OCN_DEV void gelu_both(float x, float& g, float& dg) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    g = x * cdf;
+    dg = fmaf(x * 0.39894228040143268f, e, cdf);
+}
 OCN_DEV float dgelu_f(float x) {
     float cdf, e;
     gelu_parts(x, cdf, e);

@@ -107,14 +107,15 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     check(tag + " resid", out, ref + bias + resid, rel=2e-5)
     aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     out = ops.gemm_nt(ops.EPI_BIAS_GELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=bias, aux=aux)
-    pre = ref + bias
-    check(tag + " gelu.pre", aux, pre, bf16_out=True)
-    check(tag + " gelu.out", out, torch.nn.functional.gelu(pre), bf16_out=True, abs_tol=1e-3)
-    fpre = bf(torch.randn(M, N, generator=g)).to(dev)
-    out = ops.gemm_nt(ops.EPI_DGELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), aux=fpre)
-    x = fpre.float().requires_grad_(True)
-    torch.nn.functional.gelu(x).backward(torch.ones_like(x))
-    check(tag + " dgelu", out, ref * x.grad, bf16_out=True, abs_tol=1e-3)
+    pre = (ref + bias).requires_grad_(True)
+    act = torch.nn.functional.gelu(pre)
+    act.backward(torch.ones_like(act))
+    # the forward epilogue saves gelu'(pre-activation) (what the backward multiplies by), not the pre-activation itself
+    check(tag + " gelu.saved_derivative", aux, pre.grad, bf16_out=True, abs_tol=1e-3)
+    check(tag + " gelu.out", out, act.detach(), bf16_out=True, abs_tol=1e-3)
+    dsaved = bf(torch.randn(M, N, generator=g)).to(dev)
+    out = ops.gemm_nt(ops.EPI_DGELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), aux=dsaved)
+    check(tag + " dgelu", out, ref * dsaved.float(), bf16_out=True, abs_tol=1e-3)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
@@ -141,13 +142,14 @@ def test_gemm_nt_every_kernel_variant(dev, variant, M, N, K):
         out = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, b, torch.empty(M, N, device=dev), bias=bias, resid=resid)
         check(tag + " resid", out, ref + bias + resid, rel=2e-5)
         out = ops.gemm_nt(ops.EPI_DGELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), aux=fpre)
-        x = fpre.float().requires_grad_(True)
-        torch.nn.functional.gelu(x).backward(torch.ones_like(x))
-        check(tag + " dgelu", out, ref * x.grad, bf16_out=True, abs_tol=1e-3)
+        check(tag + " dgelu", out, ref * fpre.float(), bf16_out=True, abs_tol=1e-3)  # aux = the saved gelu'(pre-activation)
         aux = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         out = ops.gemm_nt(ops.EPI_BIAS_GELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=bias, aux=aux)
-        check(tag + " gelu.out", out, torch.nn.functional.gelu(ref + bias), bf16_out=True, abs_tol=1e-3)
-        check(tag + " gelu.pre", aux, ref + bias, bf16_out=True)
+        pre = (ref + bias).requires_grad_(True)
+        act = torch.nn.functional.gelu(pre)
+        act.backward(torch.ones_like(act))
+        check(tag + " gelu.out", out, act.detach(), bf16_out=True, abs_tol=1e-3)
+        check(tag + " gelu.saved_derivative", aux, pre.grad, bf16_out=True, abs_tol=1e-3)
     finally:
         _lib.call("ocn_set_gemm_variant", 0)
 

@@ -139,10 +139,10 @@ def ntstore_sweep():
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
             aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
-            for mask in (0, 2, 0, 2):
+            for mask in (0, 2, 4, 0, 2, 4):
                 _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
                 ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
-                row.append(f"{'nt' if mask else 'wb'} {2.0 * M * N * K / ms / 1e9:5.0f}")
+                row.append(f"{ {0: 'wb', 2: 'nt', 4: 'drain'}[mask]} {2.0 * M * N * K / ms / 1e9:5.0f}")
             print(f"{name:9s} epi {epi} (TF/s): " + " | ".join(row), flush=True)
             del out, resid, aux
         del a, b
