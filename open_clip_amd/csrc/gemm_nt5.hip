@@ -153,7 +153,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     for (int it = 0; it < 4; ++it) {
                         const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
                         const unsigned off = (unsigned)(row * a.ldc) * 2u + col_off;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, AUX & 2);
                     }
                 }
             }
@@ -174,9 +174,9 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 if (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    ex[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, 0));
+                    ex[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
                 } else if (EPI == OCN_EPI_DGELU) {
-                    const bf16x4 p4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_aux, byte_off(blk, it, 2u), 0, 0));
+                    const bf16x4 p4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_aux, byte_off(blk, it, 2u), 0, (AUX & 8) ? 2 : 0));
                     ex[it] = (f32x4){bf2f(p4[0]), bf2f(p4[1]), bf2f(p4[2]), bf2f(p4[3])};
                 }
             }
@@ -200,13 +200,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             for (int it = 0; it < 4; ++it) {
                 const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
                 if (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, AUX & 2);
                 } else if (EPI == OCN_EPI_DGELU) {
                     const f32x4 dg = ex[it];  // gelu'(pre-activation), saved by the forward epilogue
                     const bf16x4 o4 = {f2bf(v[0] * dg[0]), f2bf(v[1] * dg[1]), f2bf(v[2] * dg[2]), f2bf(v[3] * dg[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, AUX & 2);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, AUX & 2);
                 }
             }
         }
@@ -215,7 +215,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 
 // DBG = developer build of the same kernel that logs a per-tile timeline into a.aux (tools/gemm_trace.py; plain bf16
 // epilogue only); the production instantiation folds it away.
-// AUX = cache-policy bits of the epilogue's stores (0 = default write-back, 2 = non-temporal: developer experiment)
+// AUX = cache policy of the epilogue: bit 1 (2) = non-temporal stores, bit 3 (8) = non-temporal loads of the residual / saved operand
 template <int EPI, bool DBG, int AUX = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,16 +533,31 @@ int launch5(GemmNtArgs a, hipStream_t st) {
         OCN_CHECK_LAUNCH("ocn_gemm_nt");
         return OCN_OK;
     }
-    if (a.ablate & 2) {  // developer experiment: non-temporal epilogue stores
-        static bool nt_attr_set = false;
-        if (!nt_attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-            nt_attr_set = true;
-        }
-        hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, 2>), dim3(grid), dim3(512), LDS_BYTES, st, a);
-        OCN_CHECK_LAUNCH("ocn_gemm_nt");
-        return OCN_OK;
+    // Cache policy of the epilogue's stores: the two-output GELU epilogue writes 256 KiB per tile that nothing re-reads before
+    // they are long evicted -- streamed past the L2 (non-temporal) they stop displacing the operand panels: +5..8 % on that
+    // kernel, -2 % on the dGELU / residual ones (profiles/r01_nt5_cache_policy_sweep.txt).  Developer knob bits 2 / 8 flip the
+    // store / load choice.
+    //   stores: non-temporal for the GELU epilogue and for wide bf16 outputs (N >= 1024: the QKV projections, +4..6 %);
+    //   loads:  non-temporal for the fp32 residual, which is read exactly once (+1..3 %); the saved GELU derivative of the dGELU
+    //           epilogue is better left cacheable (-5 % otherwise).
+    const bool st_nt = (EPI == OCN_EPI_BIAS_GELU) || (EPI == OCN_EPI_BF16 && a.N >= 1024);
+    const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32);
+    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0);
+#define OCN_NT5_LAUNCH_AUX(AUXV)                                                                                                   \
+    if (aux == (AUXV)) {                                                                                                           \
+        static bool set_ = false;                                                                                                  \
+        if (!set_) {                                                                                                               \
+            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, AUXV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+            set_ = true;                                                                                                           \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, AUXV>), dim3(grid), dim3(512), LDS_BYTES, st, a);                           \
+        OCN_CHECK_LAUNCH("ocn_gemm_nt");                                                                                           \
+        return OCN_OK;                                                                                                             \
     }
+    OCN_NT5_LAUNCH_AUX(2)
+    OCN_NT5_LAUNCH_AUX(8)
+    OCN_NT5_LAUNCH_AUX(10)
+#undef OCN_NT5_LAUNCH_AUX
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -8,6 +8,7 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+extern int g_ocn_tuning[16];
 namespace {
 
 template <int NV>
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-template <int NV, bool DY32>
+// NT: x and the residual gradient (read once, long after they were written) are loaded and the fp32 dx (read again only by the
+// next LayerNorm backward, two GEMMs later) is stored with the non-temporal policy; dy and the bf16 dx, which the neighbouring
+// GEMMs produce / consume right away, keep the default one.
+template <int NV, bool DY32, bool NT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dyv, const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             if (c < C) {
                 // the residual gradient is fetched together with x and dy (not after the row reductions): one memory
                 // round trip per row instead of two
-                if (dres) dr[i] = *(const f32x4*)(dres + (size_t)row * C + c);
-                const f32x4 xv = *(const f32x4*)(x + (size_t)row * C + c);
+                if (dres) dr[i] = NT ? __builtin_nontemporal_load((const f32x4*)(dres + (size_t)row * C + c)) : *(const f32x4*)(dres + (size_t)row * C + c);
+                const f32x4 xv = NT ? __builtin_nontemporal_load((const f32x4*)(x + (size_t)row * C + c)) : *(const f32x4*)(x + (size_t)row * C + c);
                 f32x4 dy;
                 if (DY32) {
                     dy = *(const f32x4*)((const float*)dyv + (size_t)row * C + c);
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
                 o = o + dr[i];
-                if (dx32) *(f32x4*)(dx32 + (size_t)row * C + c) = o;
+                if (dx32) {
+                    if (NT) __builtin_nontemporal_store(o, (f32x4*)(dx32 + (size_t)row * C + c));
+                    else *(f32x4*)(dx32 + (size_t)row * C + c) = o;
+                }
                 if (dx16) {
                     bf16x4 o4 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
                     *(bf16x4*)(dx16 + (size_t)row * C + c) = o4;
@@ -176,8 +183,14 @@ void launch_fwd(hipStream_t st, const float* x, const float* w, const float* b, 
 template <int NV>
 void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                 const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C) {
-    if (dy_is_f32) ln_bwd_kernel<NV, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
-    else ln_bwd_kernel<NV, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+    const bool nt = g_ocn_tuning[8] != 1;  // developer knob 8 = 1: default cache policy everywhere
+    if (dy_is_f32) {
+        if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+        else ln_bwd_kernel<NV, true, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+    } else {
+        if (nt) ln_bwd_kernel<NV, false, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+        else ln_bwd_kernel<NV, false, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+    }
 }
 
 }  // namespace

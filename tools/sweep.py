@@ -126,9 +126,11 @@ def tn_sweep():
 
 
 def ntstore_sweep():
-    """epilogue stores with the non-temporal cache policy (developer knob bit 2 of the ablation mask)"""
-    cases = [("img fc", Mi, 3072, 768, [0, 1, 3]), ("img out", Mi, 768, 768, [2]), ("img proj", Mi, 768, 3072, [2]),
-             ("txt fc", Mt, 2048, 512, [1, 3]), ("txt out", Mt, 512, 512, [2])]
+    """cache policy of the epilogue: knob bit 2 flips non-temporal stores (default: on for the GELU epilogue only), bit 8 makes
+    the loads of the residual / saved operand non-temporal"""
+    cases = [("img qkv", Mi, 2304, 768, [0]), ("img dh2", Mi, 768, 3072, [0]), ("img da", Mi, 768, 768, [0]), ("img dh1", Mi, 768, 2304, [0]),
+             ("img fc", Mi, 3072, 768, [1, 3]), ("img out", Mi, 768, 768, [2]), ("img proj", Mi, 768, 3072, [2]),
+             ("txt qkv", Mt, 1536, 512, [0]), ("txt dh2", Mt, 512, 2048, [0]), ("txt fc", Mt, 2048, 512, [1, 3]), ("txt out", Mt, 512, 512, [2])]
     for name, M, N, K, epis in cases:
         a = torch.randn(M, K, device=dev).bfloat16()
         b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
@@ -139,14 +141,32 @@ def ntstore_sweep():
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
             aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
-            for mask in (0, 2, 4, 0, 2, 4):
+            for mask in (0, 2, 8, 10, 0, 2, 8, 10):
                 _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
                 ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
-                row.append(f"{ {0: 'wb', 2: 'nt', 4: 'drain'}[mask]} {2.0 * M * N * K / ms / 1e9:5.0f}")
+                row.append(f"{ {0: 'default', 2: 'flip-st', 8: 'nt-ld', 10: 'flip-st+nt-ld'}[mask]} {2.0 * M * N * K / ms / 1e9:5.0f}")
             print(f"{name:9s} epi {epi} (TF/s): " + " | ".join(row), flush=True)
             del out, resid, aux
         del a, b
     _lib.call("ocn_set_gemm_variant", 0)
+
+
+def ln_sweep():
+    """LayerNorm backward with / without the non-temporal policy on its read-once operands (developer knob 8)"""
+    for M, C in [(Mi, 768), (Mt, 512)]:
+        x, dres = torch.randn(M, C, device=dev), torch.randn(M, C, device=dev)
+        dy = torch.randn(M, C, device=dev).bfloat16()
+        w = torch.ones(C, device=dev)
+        mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
+        dw, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        row = []
+        gb = M * C * 16 / 1e9
+        for knob in (0, 1, 0, 1):
+            _lib.call("ocn_set_tuning", 8, knob)
+            ms = timeit(lambda: ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=dres, want_f32=True, want_bf16=True))
+            row.append(f"{'default' if knob else 'non-temporal'} {ms:.3f} ms ({gb / ms:.2f} TB/s)")
+        _lib.call("ocn_set_tuning", 8, 0)
+        print(f"ln_bwd [{M}x{C}]: " + " | ".join(row), flush=True)
 
 
 def stagger_sweep():
@@ -179,6 +199,8 @@ if __name__ == "__main__":
         attn_sweep()
     if what in ("all", "nt"):
         nt_sweep()
+    if what in ("all", "ln"):
+        ln_sweep()
     if what in ("all", "ntstore"):
         ntstore_sweep()
     if what in ("all", "stagger"):
