@@ -60,10 +60,16 @@ int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW,
 /* tuning hook (process-global; tools/gemm_bench.py and the tests use it to cover every kernel):
  *   bits 0..3  NT kernel: 0 auto, 1 128x128 two-stage, 2 256x256 two-stage, 3 256x128 two-stage, 4 256x256 4-stage ring
  *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
- *   bits 8..   developer ablation mask of the ring kernel (timing experiments only; results are wrong) */
+ *   bits 8..   developer knobs of the persistent NT kernel: (v >> 8) & 1 skip GELU arithmetic (results wrong), & 2 / & 8 flip the
+ *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 64 timeline
+ *              build; (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off) */
 int ocn_set_gemm_variant(int nt_variant);
-/* developer knobs (process-global, timing experiments only; key 1 = attention-backward ablation mask:
- *   1 skip the input staging, 2 skip the arithmetic, 4 skip the output stores -- results are wrong when non-zero) */
+/* developer knobs (process-global; experiments and A/B measurements of tools/sweep.py, never needed by a user):
+ *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)
+ *   key 2  attention backward: 3 = the 168-VGPR build (3 waves per SIMD)      key 4  wgrad GEMM: 1 = skip the atomic epilogue
+ *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
+ *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
+ *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads */
 int ocn_set_tuning(int key, int value);
 
 /* ---- casts -------------------------------------------------------------------------------------

@@ -28,12 +28,16 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
 // stage rows [0, LP) (clamped to L-1) of one head's 64-wide column block into LDS; all waves cooperate
+// NTL: non-temporal policy for the head's rows (read by this workgroup only) -- measured no faster than the default policy
+// (profiles/r01_attn_cache_policy.txt), kept as developer knob 9 = 2 of the forward
+template <bool NTL = false>
 OCN_DEV void stage_head(const bf16* __restrict__ base, size_t row_stride, int L, int LP, char* sT, int wave, int nwaves, int lane) {
     for (int seg = wave; seg < LP / 8; seg += nwaves) {
         const int r = seg * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz_nt(r);
         const int gr = r < L ? r : L - 1;
-        glds16(base + (size_t)gr * row_stride + c * 8, (OCN_LDS void*)(sT + seg * 1024));
+        __builtin_amdgcn_global_load_lds((const OCN_GLB void*)(base + (size_t)gr * row_stride + c * 8), (OCN_LDS void*)(sT + seg * 1024), 16, 0,
+                                         NTL ? 2 : 0);
     }
 }
 
@@ -97,7 +101,7 @@ OCN_DEV void flush_tile(const char* img, int row0, int lane, bf16* base, size_t 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int MAXT>
+template <int MAXT, bool NTL>
 __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                          float* __restrict__ lse, int L, int H, int causal, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
     char* sQ = smem;
     char* sK = smem + LP * 128;
     char* sV = smem + 2 * LP * 128;
-    stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
-    stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
-    stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
+    stage_head<NTL>(qbase, rs, L, LP, sQ, wave, nwaves, lane);
+    stage_head<NTL>(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
+    stage_head<NTL>(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
 
     const int qb = wave;
     const int lr = lane & 31, lh = lane >> 5;
@@ -475,17 +479,17 @@ extern "C" int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L
     if (int e = check_attn("ocn_attn_fwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
     const int lds = 3 * nw * 32 * 128;
+    const bool ntl = g_ocn_tuning[9] == 2;
     if (nw <= 4) {
-        hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (bf16*)out, lse, L, H, causal, scale);
+        if (ntl) hipLaunchKernelGGL((attn_fwd_kernel<256, true>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, L, H, causal, scale);
+        else hipLaunchKernelGGL((attn_fwd_kernel<256, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, L, H, causal, scale);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<640>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<640, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(attn_fwd_kernel<640>, dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (bf16*)out, lse, L, H, causal, scale);
+        hipLaunchKernelGGL((attn_fwd_kernel<640, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, L, H, causal, scale);
     }
     OCN_CHECK_LAUNCH("ocn_attn_fwd");
     return OCN_OK;

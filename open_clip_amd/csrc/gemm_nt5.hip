@@ -321,8 +321,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
             if (ab_i + 1 < my_tiles) set_ab(++ab_i);
         }
     };
-#define DMA_A1(J, P) DMA(dA1, voA, a1_k + a_half, A_SLOT(1, P), J)
-#define DMA_A0(J, P) DMA(dA0, voA, ab_k, A_SLOT(0, P), J)
+    // the A panel is used by the `band` workgroups of one tile row and then dead, B panels are re-used round after round:
+    // (AUX & 16) fetches A with the non-temporal policy so that it is the A lines the L2 gives up first (developer experiment)
+#define DMA_NT(DESC, VOFF, SOFF, SLOT, J)                                                                      \
+    {                                                                                                          \
+        unsigned keep_;                                                                                        \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen nt lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_)                                                                            \
+                     : "v"(VOFF[J]), "s"(DESC), "s"(wave_dst + (SLOT) + (J)*1024), "s"(SOFF)                    \
+                     : "memory");                                                                              \
+    }
+#define DMA_A1(J, P) { if constexpr ((AUX & 16) != 0) DMA_NT(dA1, voA, a1_k + a_half, A_SLOT(1, P), J) else DMA(dA1, voA, a1_k + a_half, A_SLOT(1, P), J) }
+#define DMA_A0(J, P) { if constexpr ((AUX & 16) != 0) DMA_NT(dA0, voA, ab_k, A_SLOT(0, P), J) else DMA(dA0, voA, ab_k, A_SLOT(0, P), J) }
 #define DMA_B0(J, P) DMA(dB, voB, ab_k, B_SLOT(0, P), J)
 #define DMA_B1(J, P) DMA(dB, voB, ab_k + b_half, B_SLOT(1, P), J)
 
@@ -469,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 #undef RD_A
 #undef RD_B
 #undef DMA
+#undef DMA_NT
 #undef DMA_A1
 #undef DMA_A0
 #undef DMA_B0
@@ -542,7 +553,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     //           epilogue is better left cacheable (-5 % otherwise).
     const bool st_nt = (EPI == OCN_EPI_BIAS_GELU) || (EPI == OCN_EPI_BF16 && a.N >= 1024);
     const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32);
-    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0);
+    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0) | ((a.ablate & 16) ? 16 : 0);
 #define OCN_NT5_LAUNCH_AUX(AUXV)                                                                                                   \
     if (aux == (AUXV)) {                                                                                                           \
         static bool set_ = false;                                                                                                  \
@@ -557,6 +568,9 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     OCN_NT5_LAUNCH_AUX(2)
     OCN_NT5_LAUNCH_AUX(8)
     OCN_NT5_LAUNCH_AUX(10)
+    OCN_NT5_LAUNCH_AUX(16)
+    OCN_NT5_LAUNCH_AUX(18)
+    OCN_NT5_LAUNCH_AUX(24)
 #undef OCN_NT5_LAUNCH_AUX
     static bool attr_set = false;
     if (!attr_set) {

@@ -62,9 +62,13 @@ def attn_sweep():
         qkv = torch.randn(B * L, 3 * C, device=dev).bfloat16()
         do = torch.randn(B * L, C, device=dev).bfloat16()
         out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125)
-        ms_f = timeit(lambda: ops.attn_fwd(qkv, B, L, H, causal, 0.125))
         gb_f = B * L * C * 2 * 4 / 1e9
-        row = [f"fwd {ms_f:.3f} ms ({gb_f / ms_f:.2f} TB/s)"]
+        row = []
+        for knob in (0, 2, 0, 2):  # developer knob 9 = 2: non-temporal policy for the forward's LDS-DMA loads
+            _lib.call("ocn_set_tuning", 9, knob)
+            ms_f = timeit(lambda: ops.attn_fwd(qkv, B, L, H, causal, 0.125))
+            row.append(f"fwd[{'nt' if knob else 'default'}] {ms_f:.3f} ms ({gb_f / ms_f:.2f} TB/s)")
+        _lib.call("ocn_set_tuning", 9, 0)
         gb_b = B * L * C * 2 * 8 / 1e9
         for mask in (0, 1, 2, 4, 3, 5, 6, 7):
             _lib.call("ocn_set_tuning", 1, mask)
@@ -141,10 +145,10 @@ def ntstore_sweep():
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
             aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
-            for mask in (0, 2, 8, 10, 0, 2, 8, 10):
+            for mask in (0, 16, 0, 16, 0, 16):
                 _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
                 ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
-                row.append(f"{ {0: 'default', 2: 'flip-st', 8: 'nt-ld', 10: 'flip-st+nt-ld'}[mask]} {2.0 * M * N * K / ms / 1e9:5.0f}")
+                row.append(f"{ {0: 'default', 16: 'A-nt'}[mask]} {2.0 * M * N * K / ms / 1e9:5.0f}")
             print(f"{name:9s} epi {epi} (TF/s): " + " | ".join(row), flush=True)
             del out, resid, aux
         del a, b
