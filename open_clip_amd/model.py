@@ -555,6 +555,35 @@ class NativeCLIP(nn.Module):
         return image_features, text_features, self.logit_scale.exp()
 
 
+_TEXT_KEYS = ("text_projection", "positional_embedding", "token_embedding", "transformer", "ln_final")
+
+
+def convert_from_custom_text_state_dict(state_dict: dict) -> dict:
+    """Inverse of the reference's ``convert_to_custom_text_state_dict`` (model.py:772-787): checkpoints written by a
+    ``CustomTextCLIP`` keep the text tower under ``text.*``; NativeCLIP uses the ``CLIP`` layout (text tower unpacked onto the
+    model, model.py:351-360).  ``text.attn_mask`` (a persistent buffer there) is dropped."""
+    if not any(k.startswith("text.") for k in state_dict):
+        return state_dict
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith("text."):
+            k2 = k[len("text."):]
+            if k2 == "attn_mask":
+                continue
+            if not any(k2.startswith(p) for p in _TEXT_KEYS):
+                raise KeyError(f"unexpected text-tower key {k!r} (only the built-in text transformer is supported)")
+            k = k2
+        out[k] = v
+    return out
+
+
+def convert_to_custom_text_state_dict(state_dict: dict) -> dict:
+    """the reference's direction (model.py:772-787), for writing checkpoints a ``CustomTextCLIP`` can load"""
+    if "text_projection" not in state_dict:
+        return state_dict
+    return {("text." + k if any(k.startswith(p) for p in _TEXT_KEYS) else k): v for k, v in state_dict.items()}
+
+
 def create_model(model_name: str, pretrained: Optional[str] = None, precision: str = "amp_bf16", device="cuda",
                  output_dict: Optional[bool] = None, init_logit_scale=None, init_logit_bias=None, **model_kwargs):
     """Counterpart of ``open_clip.factory.create_model`` (factory.py:264-287) for the native path.
@@ -575,5 +604,5 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
         sd = torch.load(pretrained, map_location="cpu", weights_only=True)
         sd = sd.get("state_dict", sd)
         sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-        model.load_state_dict(sd, strict=True)
+        model.load_state_dict(convert_from_custom_text_state_dict(sd), strict=True)
     return model.to(device)

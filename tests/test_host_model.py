@@ -74,8 +74,14 @@ def test_forward_on_cpu_fails_loudly():
 def test_create_model_rejects_unsupported():
     with pytest.raises(RuntimeError, match="not found"):
         create_model("RN50", device="cpu")
-    with pytest.raises(NotImplementedError, match="head_dim 64"):
-        create_model("ViT-H-14", device="meta")
+    m = create_model("ViT-H-14", device="meta")  # head_dim 80: the generic attention kernels (csrc/attention_generic.hip)
+    assert m.visual.transformer.resblocks[0].attn.head_dim == 80 and m.visual.transformer.resblocks[0].n_head == 16
+    from open_clip_amd.configs import add_model_config
+    odd = get_model_config("tiny-test")
+    odd["vision_cfg"].update(width=144, head_width=72)
+    add_model_config("odd-head", odd)
+    with pytest.raises(NotImplementedError, match="head_dim 64 / 80 / 96 / 128"):
+        create_model("odd-head", device="meta")
     with pytest.raises(ValueError, match="precision"):
         create_model("tiny-test", precision="fp16", device="cpu")
 
@@ -88,3 +94,45 @@ def test_synthetic_batch_layout():
     assert (t[:, 0] == 49406).all() and ((t == 49407).sum(-1) == 1).all()
     eot = t.argmax(-1)
     assert (eot >= 8).all() and all((t[i, eot[i] + 1:] == 0).all() for i in range(16))
+
+
+def test_checkpoint_file_roundtrip_and_custom_text_key_layout(tmp_path):
+    """8f-4: a checkpoint written to disk loads back bit-equal through ``create_model(pretrained=...)`` in the layouts the reference
+    produces: bare ``CLIP`` keys, a ``{'state_dict': ...}`` wrapper with DDP's ``module.`` prefix, and ``CustomTextCLIP``'s
+    ``text.*`` keys (model.py:772-787 run backwards); the forward converter reproduces the reference's mapping."""
+    from open_clip_amd.configs import add_model_config
+    from open_clip_amd.model import convert_from_custom_text_state_dict, convert_to_custom_text_state_dict
+    cfg = get_model_config("tiny-test")
+    add_model_config("tiny-test-ckpt", cfg)
+    sd = init_state_dict(cfg, 5, perturb=True)
+    custom = convert_to_custom_text_state_dict(sd)
+    assert "text.token_embedding.weight" in custom and "text.transformer.resblocks.0.ln_1.weight" in custom
+    assert "visual.conv1.weight" in custom and "logit_scale" in custom and "text_projection" not in custom
+    back = convert_from_custom_text_state_dict(dict(custom, **{"text.attn_mask": torch.zeros(16, 16)}))
+    assert back.keys() == sd.keys() and all(torch.equal(back[k], sd[k]) for k in sd)
+    variants = {"plain.pt": sd, "wrapped.pt": {"state_dict": {"module." + k: v for k, v in sd.items()}, "epoch": 3}, "custom.pt": custom}
+    for name, obj in variants.items():
+        path = str(tmp_path / name)
+        torch.save(obj, path)
+        m = create_model("tiny-test-ckpt", pretrained=path, device="cpu")
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, sd[k]), (name, k)
+    with pytest.raises(KeyError, match="unexpected text-tower key"):
+        convert_from_custom_text_state_dict({"text.proj.weight": torch.zeros(1)})
+
+
+def test_optimizer_state_dict_roundtrip():
+    """NativeAdamW is a torch.optim.Optimizer: its state (step, exp_avg, exp_avg_sq) and param groups survive
+    state_dict() / load_state_dict() (what task/checkpoint.py stores)."""
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference
+    model, _ = _tiny()
+    opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=1e-3)
+    for p in model.parameters():
+        st = opt.state[p]
+        st["step"], st["exp_avg"], st["exp_avg_sq"] = 7, torch.full_like(p, 0.5), torch.full_like(p, 0.25)
+    blob = opt.state_dict()
+    opt2 = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4)
+    opt2.load_state_dict(blob)
+    assert opt2.param_groups[0]["lr"] == 1e-3 and opt2.param_groups[1]["weight_decay"] == 0.2
+    for p in model.parameters():
+        assert opt2.state[p]["step"] == 7 and torch.equal(opt2.state[p]["exp_avg"], torch.full_like(p, 0.5))
