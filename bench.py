@@ -206,7 +206,8 @@ def main():
         value = B * world / (elapsed / args.steps)
         flops_pair = 3 * FWD_GFLOP_PER_PAIR.get(args.model, 0.0) * (4 / 3 if args.grad_checkpointing else 1.0)
         line = {
-            "metric": "image-text pairs/sec (whole node), ViT-B-32 gbs=32768 at 1/2/4/8 GPUs", "value": round(value, 1),
+            "metric": ("image-text pairs/sec (whole node), ViT-B-32 gbs=32768 at 1/2/4/8 GPUs" if args.model == "ViT-B-32" and not args.siglip
+                       else f"image-text pairs/sec (whole node), {args.model}{' SigLIP' if args.siglip else ''}"), "value": round(value, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} {'SigLIPTask' if args.siglip else 'CLIPTask'}-equivalent train step (fwd+{'SigLipLoss' if args.siglip else 'ClipLoss'}+bwd+AdamW+clamp), amp_bf16 policy, "
