@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--naive-global-loss", action="store_true", help="N>1: every rank evaluates the full N x N logits (the reference's "
                     "redundant form) instead of its own rows (same loss and gradients; tests/test_dist_loss_gloo.py, test_ddp_gpu.py)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="developer: value for ocn_set_gemm_variant (kernel choice / ablation knobs)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE", help="developer: ocn_set_tuning(KEY, VALUE) before the run")
     ap.add_argument("--dist-backend", default="nccl", help="developer: 'gloo' + OCN_BENCH_ONE_DEVICE=1 runs N ranks on one GPU")
     return ap.parse_args()
 
@@ -139,9 +140,13 @@ def main():
     from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
     from open_clip_amd.synth import init_state_dict, synthetic_batch
 
-    if args.gemm_variant:
+    if args.gemm_variant or args.tuning:
         from open_clip_amd import _lib
-        _lib.call("ocn_set_gemm_variant", args.gemm_variant)
+        if args.gemm_variant:
+            _lib.call("ocn_set_gemm_variant", args.gemm_variant)
+        for kv in args.tuning:
+            k, v = kv.split("=")
+            _lib.call("ocn_set_tuning", int(k), int(v))
     cfg = get_model_config(args.model)
     torch.manual_seed(0)
     extra = dict(init_logit_scale=math.log(10), init_logit_bias=-10.0) if args.siglip else {}  # main.py:259-261

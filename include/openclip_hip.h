@@ -69,8 +69,12 @@ int ocn_set_gemm_variant(int nt_variant);
  *   key 2  attention backward: 3 = the 168-VGPR build (3 waves per SIMD)      key 4  wgrad GEMM: 1 = skip the atomic epilogue
  *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
  *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
- *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads */
+ *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
+ *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 3)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one) */
 int ocn_set_tuning(int key, int value);
+/* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
+ * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */
+int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_stream_t stream);
 
 /* ---- casts -------------------------------------------------------------------------------------
  * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */

@@ -19,6 +19,7 @@ SIGNATURES = {
     "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
     "ocn_set_gemm_variant": [_i],
     "ocn_set_tuning": [_i, _i],
+    "ocn_debug_occupy": [_i, _i, _p, _p],
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
     "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],

@@ -52,6 +52,33 @@ __global__ void probe_tr16_kernel(const bf16* in, bf16* out) {
 }
 }  // namespace
 
+namespace {
+// developer probe: `n` workgroups that each hold a CU's LDS for `ticks` (100 MHz) -- stands in for collective kernels that occupy
+// CUs while a persistent GEMM is launched (tools/occupancy_hazard_probe.py)
+__global__ void occupy_kernel(long long ticks, int* sink) {
+    extern __shared__ char smem[];
+    const long long until = wall_clock64() + ticks;
+    int acc = 0;
+    while (wall_clock64() < until) {
+        __builtin_amdgcn_s_sleep(32);
+        acc += smem[threadIdx.x];
+    }
+    if (acc == 0x7fffffff) *sink = acc;
+}
+}  // namespace
+
+extern "C" int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_stream_t stream) {
+    OCN_CHECK_ARG(n_workgroups > 0 && micros > 0 && sink, "ocn_debug_occupy: bad arguments");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_workgroups), dim3(64), 140 * 1024, (hipStream_t)stream, (long long)micros * 100, sink);
+    OCN_CHECK_LAUNCH("ocn_debug_occupy");
+    return OCN_OK;
+}
+
 extern "C" int ocn_probe_mfma32(const void* a, const void* b, float* c, ocn_stream_t stream) {
     hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, c);
     OCN_CHECK_LAUNCH("ocn_probe_mfma32");

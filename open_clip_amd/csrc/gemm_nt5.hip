@@ -487,6 +487,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 }
 
 int g_num_cu = 0;
+}  // namespace
+extern int g_ocn_tuning[16];
+namespace {
 
 // Band width of the tile walk (see tile_origin).  L2-miss read model per launch, in bytes:
 //   row-major over all of N:  A once + B once per round of tiles per XCD when B does not stay in L2  = A + (ntiles / 32) * B
@@ -533,7 +536,13 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
     a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
     a.stagger = nt5_stagger<EPI>(a.ntiles, a.K, (a.ablate >> 13) & 63);
-    const int grid = a.ntiles < g_num_cu ? a.ntiles : g_num_cu;
+    // Three workgroups per CU, each with a third of the tiles (they queue behind each other on a CU; only one fits at a time).
+    // Same steady-state time as one per CU (profiles/r01_nt5_workgroups_per_cu_sweep.txt), but a workgroup that cannot start with
+    // the rest -- a CU held by another stream's kernel: the wgrads of the side stream, the collective kernels of a multi-GPU
+    // step -- then delays the launch by a third of its length instead of by half to all of it (measured with one CU held: +50 %
+    // at one workgroup per CU, +11..18 % at three; profiles/r01_persistent_gemm_occupancy_hazard.txt).  Developer knob 10 = k.
+    const int per_cu = g_ocn_tuning[10] > 0 ? g_ocn_tuning[10] : 3;
+    const int grid = a.ntiles < g_num_cu * per_cu ? a.ntiles : g_num_cu * per_cu;
     if (a.ablate & 64) {  // developer build: per-tile timeline into a side buffer passed in a.resid/a.aux (tools/gemm_trace.py)
         static bool dbg_attr_set = false;
         if (!dbg_attr_set) {

@@ -272,7 +272,13 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     a.tiles_k = ocn_cdiv(a.K, 256);
     const int ntile = a.tiles_n * a.tiles_k;
     const int msteps = ocn_cdiv(a.M, 32);
-    int splits = g_tn5_num_cu / ntile;  // one workgroup per CU
+    int splits = g_tn5_num_cu / ntile;  // one workgroup per CU ...
+    // ... developer knob 11 = k: k per CU when the M-chunks stay long (<= 10 splits).  A workgroup that starts late because its CU
+    // is held by another stream's kernel then costs 1/k as much (one CU held: +43 % at k = 1, +7 % at k = 2;
+    // profiles/r01_persistent_gemm_occupancy_hazard.txt), but the finer split costs 4-8 % in steady state on exactly those big
+    // shapes (profiles/r01_tn5_split_sweep.txt) -- more than collectives that are active for a few percent of a step can take.
+    const int over = g_ocn_tuning[11] > 0 ? g_ocn_tuning[11] : 1;
+    if (over > 1 && splits >= 1 && splits <= 10) splits *= over;
     if (splits < 1) splits = 1;
     if (splits > msteps) splits = msteps;
     a.chunk = ocn_cdiv(msteps, splits) * 32;

@@ -125,6 +125,11 @@ def tn_sweep():
             ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
             row.append(f"{'no-epilogue' if ab else 'full'} {ms:.3f} ms ({2.0 * M * N * K / ms / 1e9:5.0f} TF/s)")
         _lib.call("ocn_set_tuning", 4, 0)
+        for k in (1, 2, 1, 2):  # M-splits per CU for the shapes with few splits (developer knob 11)
+            _lib.call("ocn_set_tuning", 11, k)
+            ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
+            row.append(f"{k}/CU {ms:.3f} ms")
+        _lib.call("ocn_set_tuning", 11, 0)
         print(f"tn {name:9s} dW[{N},{K}]: " + " | ".join(row), flush=True)
         del a, b
 
@@ -173,6 +178,33 @@ def ln_sweep():
         print(f"ln_bwd [{M}x{C}]: " + " | ".join(row), flush=True)
 
 
+def percu_sweep():
+    """persistent NT GEMM launched with k workgroups per CU (developer knob 10), steady-state timing on the step's shapes"""
+    cases = [("img qkv", Mi, 2304, 768, 0), ("img dh2", Mi, 768, 3072, 0), ("img da", Mi, 768, 768, 0), ("img dh1", Mi, 768, 2304, 0),
+             ("img fc", Mi, 3072, 768, 1), ("img dgelu", Mi, 3072, 768, 3), ("img out", Mi, 768, 768, 2), ("img proj", Mi, 768, 3072, 2),
+             ("txt qkv", Mt, 1536, 512, 0), ("txt dh2", Mt, 512, 2048, 0), ("txt da", Mt, 512, 512, 0), ("txt dh1", Mt, 512, 1536, 0),
+             ("txt fc", Mt, 2048, 512, 1), ("txt dgelu", Mt, 2048, 512, 3), ("txt out", Mt, 512, 512, 2), ("txt proj", Mt, 512, 2048, 2)]
+    tot = {}
+    for name, M, N, K, epi in cases:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, device=dev)
+        f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+        resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
+        aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+        row = []
+        for k in (1, 2, 3, 4, 1, 2):
+            _lib.call("ocn_set_tuning", 10, k)
+            ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
+            row.append(f"{k}/CU {ms:.3f} ms")
+            tot[k] = tot.get(k, 0.0) + ms
+        print(f"{name:10s} epi {epi}: " + " | ".join(row), flush=True)
+        del a, b, out, resid, aux
+    _lib.call("ocn_set_tuning", 10, 0)
+    print("sum over shapes (1/CU and 2/CU measured twice): " + ", ".join(f"{k}/CU {v:.3f} ms" for k, v in tot.items()), flush=True)
+
+
 def stagger_sweep():
     """start-phase stagger of the persistent NT kernel (us per phase class; 63 = off, 0 = automatic)"""
     cases = [("img fc", Mi, 3072, 768, [0, 1, 3]), ("img out", Mi, 768, 768, [2]), ("img proj", Mi, 768, 3072, [0, 2]),
@@ -203,6 +235,8 @@ if __name__ == "__main__":
         attn_sweep()
     if what in ("all", "nt"):
         nt_sweep()
+    if what in ("all", "percu"):
+        percu_sweep()
     if what in ("all", "ln"):
         ln_sweep()
     if what in ("all", "ntstore"):
