@@ -273,3 +273,58 @@ def test_vith14_siglip_full_size_step_runs():
         assert torch.isfinite(f).all() and float((f.norm(dim=-1) - 1).abs().max()) < 1e-3
     for n, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_training_steps_with_fused_optimizer_track_the_cpu_oracle():
+    """Four full training steps -- forward, ClipLoss, backward, fused NativeAdamW (clip + update + in-place refresh of the cached
+    bf16 operand copies), logit_scale clamp -- against the CPU oracle stepped with torch.optim.AdamW + clip_grad_norm_ on the
+    same data: the loss of every step and the final parameters must agree (a stale operand copy or a missed version bump would
+    show from the second step on)."""
+    import math
+    from open_clip_amd.loss import NativeClipLoss
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
+    from oracle import clip_oracle as O
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=41, perturb=True)
+    batches = [synthetic_batch(cfg, 8, seed=100 + i) for i in range(4)]
+    lr, wd, clip = 2e-3, 0.2, 1.0
+    model = _build(cfg, state)
+    opt = NativeAdamW(param_groups_like_reference(model, wd), lr=lr, betas=(0.9, 0.98), eps=1e-6, grad_clip_norm=clip,
+                      weight_caches=weight_caches_of(model))
+    loss_fn = NativeClipLoss()
+    ref_params = {k: torch.nn.Parameter(v.clone().float()) for k, v in state.items()}
+    skip = {"positional_embedding", "visual.positional_embedding", "visual.class_embedding"}
+    ref_opt = torch.optim.AdamW([{"params": [p for k, p in ref_params.items() if p.ndim <= 1 or k in skip], "weight_decay": 0.0},
+                                 {"params": [p for k, p in ref_params.items() if not (p.ndim <= 1 or k in skip)], "weight_decay": wd}],
+                                lr=lr, betas=(0.9, 0.98), eps=1e-6)
+    for i, b in enumerate(batches):
+        opt.zero_grad(set_to_none=True)
+        out = model(image=b["image"].cuda(), text=b["text"].cuda())
+        loss = loss_fn(**out)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            model.logit_scale.clamp_(0, math.log(100))
+        outs, grads = O.train_forward_backward(b["image"], b["text"], {k: p.detach() for k, p in ref_params.items()}, cfg)
+        for k, p in ref_params.items():
+            p.grad = grads[k]
+        torch.nn.utils.clip_grad_norm_(list(ref_params.values()), clip)
+        ref_opt.step()
+        with torch.no_grad():
+            ref_params["logit_scale"].clamp_(0, math.log(100))
+        _report(f"train-steps[{i}]: loss {float(loss.detach()):.5f} oracle {float(outs['loss']):.5f}")
+        assert abs(float(loss.detach()) - float(outs["loss"])) <= LOSS_TOL, i
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        ref, got, start = ref_params[k].detach(), p.detach().float().cpu(), state[k].float()
+        if k.endswith("attn.in_proj_bias"):  # drop the K third: its exact gradient is zero, Adam moves it by rounding noise alone
+            c = ref.numel() // 3
+            keep = torch.cat([torch.arange(0, c), torch.arange(2 * c, 3 * c)])
+            ref, got, start = ref[keep], got[keep], start[keep]
+        moved = (ref - start).norm()
+        err = (got - ref).norm()
+        # Adam turns a gradient into a step of ~lr per element whatever its size, so elements whose gradient is (nearly) rounding
+        # noise -- the K third of in_proj_bias (softmax is invariant to it: exact gradient zero), embedding rows of rare tokens --
+        # move differently in any two implementations; the bound only has to catch a wrong update (error ~ the movement itself)
+        bound = 0.35
+        assert float(err) <= bound * float(moved) + 1e-6, (k, float(err), float(moved))
