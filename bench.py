@@ -222,6 +222,7 @@ def main():
                        "model": args.model, "global_batch": B * world, "local_batch": B, "parallelism": f"dp{world}",
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             "step_model_tflops_per_gpu": round(value / world * flops_pair / 1e3, 1),
+            "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated() / 1e9, 1),
         }
         if not args.no_roofline:
             s = timer.summary()

@@ -70,7 +70,7 @@ int ocn_set_gemm_variant(int nt_variant);
  *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
  *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
  *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
- *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 3)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one) */
+ *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one) */
 int ocn_set_tuning(int key, int value);
 /* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
  * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */

@@ -13,6 +13,7 @@ struct GemmNtArgs {
     float alpha;
     int tiles_n, ntiles;
     int stagger; // start offset between the 4 phase classes of workgroups, in 100 MHz ticks (0 = none; gemm_nt5.hip)
+    int first_wave;  // workgroups [0, first_wave) start together (one per CU) and are the ones that get staggered
     int band;    // tile walk order: column bands of `band` n-tiles, row-major inside a band (gemm_nt5.hip)
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
 };

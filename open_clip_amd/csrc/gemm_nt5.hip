@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // pipes idle (measured with the DBG timeline: 11 us per tile for the two-output GELU epilogue against 3 us for one
     // bf16 output; profiles/r01_nt5_tile_timeline.txt).  Workgroups therefore start in 4 phase classes (inside every XCD),
     // a quarter of a tile time apart, which spreads the epilogue traffic over the whole tile period.
-    if (a.stagger > 0) {
+    if (a.stagger > 0 && (int)blockIdx.x < a.first_wave) {  // later workgroups start whenever a CU frees up: already spread out
         const int phase = ((int)blockIdx.x >> 3) & 3;
         if (phase) {
             const long long until = wall_clock64() + (long long)phase * a.stagger;
@@ -536,12 +536,14 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
     a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
     a.stagger = nt5_stagger<EPI>(a.ntiles, a.K, (a.ablate >> 13) & 63);
-    // Three workgroups per CU, each with a third of the tiles (they queue behind each other on a CU; only one fits at a time).
-    // Same steady-state time as one per CU (profiles/r01_nt5_workgroups_per_cu_sweep.txt), but a workgroup that cannot start with
-    // the rest -- a CU held by another stream's kernel: the wgrads of the side stream, the collective kernels of a multi-GPU
-    // step -- then delays the launch by a third of its length instead of by half to all of it (measured with one CU held: +50 %
-    // at one workgroup per CU, +11..18 % at three; profiles/r01_persistent_gemm_occupancy_hazard.txt).  Developer knob 10 = k.
-    const int per_cu = g_ocn_tuning[10] > 0 ? g_ocn_tuning[10] : 3;
+    a.first_wave = g_num_cu;
+    // One workgroup per CU.  Developer knob 10 = k launches k per CU with 1/k of the tiles each (they queue behind each other on a
+    // CU): a workgroup that cannot start with the rest -- a CU held by another stream's kernel, e.g. a collective -- then delays the
+    // launch by 1/k of its length instead of by half of it (one CU held: +50 % at k = 1, +11..18 % at k = 3;
+    // profiles/r01_persistent_gemm_occupancy_hazard.txt).  In isolation k = 3 costs nothing
+    // (profiles/r01_nt5_workgroups_per_cu_sweep.txt), in the training step it costs 1.0 % (235.0 -> 237.4 ms, same box), which is
+    // more than collectives that are active for ~1.5 % of a step can take back -- so k = 1 stays the default.
+    const int per_cu = g_ocn_tuning[10] > 0 ? g_ocn_tuning[10] : 1;
     const int grid = a.ntiles < g_num_cu * per_cu ? a.ntiles : g_num_cu * per_cu;
     if (a.ablate & 64) {  // developer build: per-tile timeline into a side buffer passed in a.resid/a.aux (tools/gemm_trace.py)
         static bool dbg_attr_set = false;
