@@ -93,6 +93,12 @@ int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf
 int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, int M,
                       int C, ocn_stream_t stream);
+/* The same with the residual gradient exchanged as a (hi, lo) bf16 pair (value = hi + lo, 16 mantissa bits): dres may come as
+ * dres_hi / dres_lo instead of fp32, and dx_lo (with dx_bf16 as its hi half) may replace dx_f32 -- 4 bytes per element instead
+ * of 6 where the bf16 copy is needed anyway as the next GEMM's operand (hand-off between the two LayerNorm backwards of a block). */
+int ocn_layernorm_bwd_pair(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean, const float* rstd,
+                           const float* dres, const void* dres_hi, const void* dres_lo, float* dx_f32, void* dx_bf16, void* dx_lo,
+                           float* dw, float* db, int M, int C, ocn_stream_t stream);
 
 /* ---- attention core (transformer.py:199-244: head split + F.scaled_dot_product_attention) ------
  * qkv bf16 [B*L, 3*H*64] (q | k | v column blocks, heads contiguous inside each: the layout F.linear with

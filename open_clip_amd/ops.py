@@ -100,14 +100,21 @@ def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False):
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dres_pair=None, want_pair=False):
+    """``dres_pair`` = (hi, lo) bf16 tensors instead of an fp32 ``dres``; ``want_pair`` returns (None, hi, lo) instead of
+    (dx32, dx16): the residual gradient as a bf16 pair (see ocn_layernorm_bwd_pair)."""
     M, C = x.shape
     is32 = dy.dtype == F32
-    dx32 = empty((M, C), F32, x) if want_f32 else None
-    dx16 = empty((M, C), BF16, x) if want_bf16 else None
-    _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
-              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(dx32, F32, "dx32"),
-              _chk(dx16, BF16, "dx16"), _chk(dw, F32, "dw"), _chk(db, F32, "db"), M, C, _stream())
+    dx32 = empty((M, C), F32, x) if (want_f32 and not want_pair) else None
+    dx16 = empty((M, C), BF16, x) if (want_bf16 or want_pair) else None
+    dxlo = empty((M, C), BF16, x) if want_pair else None
+    hi, lo = dres_pair if dres_pair is not None else (None, None)
+    _lib.call("ocn_layernorm_bwd_pair", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
+              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(hi, BF16, "dres_hi"), _chk(lo, BF16, "dres_lo"),
+              _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"), _chk(dxlo, BF16, "dx_lo"), _chk(dw, F32, "dw"), _chk(db, F32, "db"), M, C,
+              _stream())
+    if want_pair:
+        return None, dx16, dxlo
     return dx32, dx16
 
 

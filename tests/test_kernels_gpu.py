@@ -235,6 +235,32 @@ def test_layernorm(dev, M, C):
         check(f"ln_bwd[{M}x{C},{dy_dtype}] db", db, br.grad, rel=1e-4)
 
 
+@pytest.mark.parametrize("M,C", [(400, 768), (616, 512), (37, 128)])
+def test_layernorm_bwd_residual_gradient_as_bf16_pair(dev, M, C):
+    """The residual gradient exchanged as (hi, lo) bf16 instead of fp32: hi == the bf16 twin bit for bit, hi + lo == the fp32
+    result to 2^-16 relative, and a backward that takes the pair as its dres equals one that takes the fp32 tensor."""
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x, dres = torch.randn(M, C, generator=g).to(dev), torch.randn(M, C, generator=g).to(dev)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    dy = bf(torch.randn(M, C, generator=g)).to(dev)
+    _, _, mean, rstd = ops.layernorm_fwd(x, w, torch.zeros(C, device=dev))
+    z = lambda: (torch.zeros(C, device=dev), torch.zeros(C, device=dev))
+    dw0, db0 = z()
+    dx32, dx16 = ops.layernorm_bwd(dy, x, w, mean, rstd, dw0, db0, dres=dres, want_f32=True, want_bf16=True)
+    dw1, db1 = z()
+    _, hi, lo = ops.layernorm_bwd(dy, x, w, mean, rstd, dw1, db1, dres=dres, want_pair=True)
+    assert torch.equal(hi, dx16)
+    err = (hi.float() + lo.float() - dx32).abs()
+    assert float((err / dx32.abs().clamp_min(1e-6)).max()) <= 2.0 ** -15, float(err.max())
+    dw2, db2 = z()
+    a32, a16 = ops.layernorm_bwd(dy, x, w, mean, rstd, dw2, db2, dres=dx32, want_f32=True, want_bf16=True)
+    dw3, db3 = z()
+    b32, b16 = ops.layernorm_bwd(dy, x, w, mean, rstd, dw3, db3, dres_pair=(hi, lo), want_f32=True, want_bf16=True)
+    check(f"ln_bwd pair[{M}x{C}] dx from pair vs from fp32", b32, a32, rel=2e-5)
+    assert float((b16.float() != a16.float()).float().mean()) < 0.01
+
+
 # ---------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, B, L, H, causal, D=64):
     C = H * D
