@@ -57,6 +57,14 @@ int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, vo
 int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
                       float* dbias, float alpha, ocn_stream_t stream);
 
+/* The same with a caller-provided scratch buffer: when ocn_gemm_tn_workspace_bytes(M, N, K) > 0 (many M-splits accumulating into a
+ * small dW: the out-proj / QKV weight gradients) and `workspace` holds that many bytes, every split stores its partial tile to its own
+ * slab and a second kernel sums the slabs into dW, instead of 20..60-way contended fp32 atomics.  The query returns 0 (atomics) unless
+ * developer knob 12 = 2: measured -5 % on the out-proj shapes and nothing on the training step. */
+int64_t ocn_gemm_tn_workspace_bytes(int M, int N, int K);
+int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
+                         float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream);
+
 /* tuning hook (process-global; tools/gemm_bench.py and the tests use it to cover every kernel):
  *   bits 0..3  NT kernel: 0 auto, 1 128x128 two-stage, 2 256x256 two-stage, 3 256x128 two-stage, 4 256x256 4-stage ring
  *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
@@ -70,7 +78,8 @@ int ocn_set_gemm_variant(int nt_variant);
  *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
  *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
  *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
- *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one) */
+ *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
+ *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step) */
 int ocn_set_tuning(int key, int value);
 /* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
  * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */

@@ -17,6 +17,7 @@ _p, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 SIGNATURES = {
     "ocn_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p],
     "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
+    "ocn_gemm_tn_accum_ws": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p, _l, _p],
     "ocn_set_gemm_variant": [_i],
     "ocn_set_tuning": [_i, _i],
     "ocn_debug_occupy": [_i, _i, _p, _p],
@@ -49,7 +50,7 @@ SIGNATURES = {
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }
-_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i)}
+_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_workspace_bytes": ([_i, _i, _i], _l)}
 
 _lib = None
 _lock = threading.Lock()

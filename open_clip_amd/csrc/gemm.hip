@@ -785,15 +785,29 @@ extern "C" int ocn_set_gemm_variant(int nt_variant) {
     return OCN_OK;
 }
 
+extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
+                                    float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream);
+
 extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
                                  float* dbias, float alpha, ocn_stream_t stream) {
+    return ocn_gemm_tn_accum_ws(A, lda, B, ldb, dW, ldw, M, N, K, dbias, alpha, nullptr, 0, stream);
+}
+
+extern "C" int64_t ocn_gemm_tn_workspace_bytes(int M, int N, int K) { return ocn_tn5_workspace_bytes(M, N, K); }
+
+extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
+                                    float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream) {
     OCN_CHECK_ARG(A && B && dW, "ocn_gemm_tn_accum: null operand");
     OCN_CHECK_ARG(M > 0 && N > 0 && K > 0, "ocn_gemm_tn_accum: bad shape M=%d N=%d K=%d", M, N, K);
     OCN_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "ocn_gemm_tn_accum: N, K, lda, ldb must be multiples of 8");
     OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "ocn_gemm_tn_accum: operands must be 16-byte aligned");
     GemmTnArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.dW = dW; a.dbias = dbias;
-    a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.ablate = 0;
+    a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.ablate = 0; a.nsplit = 0;
+    {   // the workspace is used only when it is exactly what the query asked for (same shape, same knobs)
+        const long need = ocn_tn5_workspace_bytes(M, N, K);
+        a.ws = (workspace && need > 0 && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dW & 15) == 0) ? (float*)workspace : nullptr;
+    }
     const bool big = (long)M * N * K >= (1L << 31) && N >= 256 && K >= 256;
     if (g_tn_variant == 3 || (g_tn_variant == 0 && big)) {  // hand-scheduled 256x256 kernel (gemm_tn5.hip); falls through if the shape does not fit it
         const int rc = ocn_launch_tn5(a, (hipStream_t)stream);

@@ -35,7 +35,11 @@ struct GemmTnArgs {
     float alpha;
     int tiles_n, tiles_k, chunk, nwg;
     int ablate;  // developer knob (ocn_set_tuning key 4): 1 = skip the atomic epilogue (timing only)
+    float* ws;   // optional workspace [splits][N][K] (+ [splits][N] for dbias behind it): partial tiles instead of atomics (gemm_tn5.hip)
+    int nsplit;
 };
 
 // hand-scheduled 256x256 TN (wgrad) kernel (gemm_tn5.hip); returns 1 if the shape is not supported by it (caller falls back)
 int ocn_launch_tn5(GemmTnArgs a, hipStream_t st);
+// bytes of workspace with which ocn_launch_tn5 replaces its atomic epilogue by partial tiles + a reduce pass (0: atomics are fine)
+long ocn_tn5_workspace_bytes(int M, int N, int K);

@@ -232,6 +232,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     // ---- epilogue: fp32 atomics (lanes of a half-wave hit 32 consecutive k = one 128-byte line) ---------------------------
     const int lr = lane & 31;
     if (a.ablate & 1) return;
+    if (a.ws) {
+        // many splits onto a small dW: the 20..60-way contended atomics are what the epilogue spends its time on (26-37 % of the
+        // launch for the out-proj shapes) -> every split stores its tile to its own slab, tn5_reduce_kernel sums the slabs
+        float* slab = a.ws + (size_t)split * a.N * a.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = (i + wk) & 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gk = k0 + wk * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gn = n0 + wn * 128 + blk * 32 + mfma32_row(r, lane);
+                    if (gn < a.N && gk < a.K) __builtin_nontemporal_store(acc[i][j][r], slab + (size_t)gn * a.K + gk);
+                }
+            }
+        }
+        // dbias stays on atomics: N values per workgroup, negligible
+        if (BIAS && lr == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gn = n0 + wn * 128 + wk * 32 + mfma32_row(r, lane);
+                if (gn < a.N) unsafeAtomicAdd(a.dbias + gn, a.alpha * accb[r]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int blk = (i + wk) & 3;
@@ -254,10 +281,52 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     }
 }
 
+// dW[n,k] += alpha * sum_s ws[s][n][k]
+__global__ __launch_bounds__(256) void tn5_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int N, int K, int ldw,
+                                                         int nsplit, float alpha) {
+    const long total4 = (long)N * K / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nsplit; ++s) acc = acc + __builtin_nontemporal_load((const f32x4*)(ws + (size_t)s * N * K) + i);
+        const long e = i * 4;
+        const int n = (int)(e / K), k = (int)(e % K);
+        float* d = dW + (size_t)n * ldw + k;
+        *(f32x4*)d = *(const f32x4*)d + acc * alpha;
+    }
+}
+
 int g_tn5_num_cu = 0;
+
+int tn5_splits(int M, int N, int K, int num_cu, int over) {
+    const int ntile = ocn_cdiv(N, 256) * ocn_cdiv(K, 256);
+    const int msteps = ocn_cdiv(M, 32);
+    int splits = num_cu / ntile;
+    if (over > 1 && splits >= 1 && splits <= 10) splits *= over;
+    if (splits < 1) splits = 1;
+    if (splits > msteps) splits = msteps;
+    const int chunk = ocn_cdiv(msteps, splits) * 32;
+    return ocn_cdiv(M, chunk);
+}
 
 }  // namespace
 extern int g_ocn_tuning[16];
+
+long ocn_tn5_workspace_bytes(int M, int N, int K) {
+    // Measured (profiles/r01_tn5_two_stage_epilogue.txt): -5 % on the two out-proj shapes, nothing on QKV, nothing on the step (the
+    // extra launch and the 64 MB scratch allocation eat it) -> off unless developer knob 12 = 2 asks for it.
+    if (g_ocn_tuning[12] != 2) return 0;
+    if (N % 8 || K % 4 || (long)M * N * K < (1L << 31) || N < 256 || K < 256) return 0;
+    int n = g_tn5_num_cu;
+    if (n == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    const int splits = tn5_splits(M, N, K, n, g_ocn_tuning[11] > 0 ? g_ocn_tuning[11] : 1);
+    // worth it when many workgroups hit every address (measured: >= 9 splits) and the slabs stay small next to the operands
+    if (splits < 9 || (long)splits * N * K * 4 > (256L << 20)) return 0;
+    return (long)splits * N * K * 4;
+}
 
 int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     if (a.N % 8 || a.K % 8 || a.lda % 8 || a.ldb % 8) return 1;
@@ -292,8 +361,16 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
+    a.nsplit = splits;
+    if (a.ws && (a.ldw % 4 || a.K % 4)) a.ws = nullptr;
     if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
     else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    if (a.ws) {
+        const long total4 = (long)a.N * a.K / 4;
+        int grid = (int)((total4 + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(tn5_reduce_kernel, dim3(grid), dim3(256), 0, st, a.ws, a.dW, a.N, a.K, a.ldw, splits, a.alpha);
+    }
     if (hipGetLastError() != hipSuccess) return OCN_ERR_LAUNCH;
     return OCN_OK;
 }

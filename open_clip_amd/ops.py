@@ -71,7 +71,10 @@ def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0):
     K = b.shape[1]
     if b.shape[0] != M or dw.shape[0] != N or dw.shape[1] != K:
         raise RuntimeError(f"gemm_tn_accum: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} dw{tuple(dw.shape)}")
-    _lib.call("ocn_gemm_tn_accum", pa, lda, pb, ldb, pw, ldw, M, N, K, _chk(dbias, F32, "dbias"), float(alpha), _stream())
+    need = _lib.load().ocn_gemm_tn_workspace_bytes(M, N, K)  # > 0: partial tiles + reduce instead of contended atomics
+    ws = torch.empty(need, dtype=torch.uint8, device=a.device) if need > 0 else None
+    _lib.call("ocn_gemm_tn_accum_ws", pa, lda, pb, ldb, pw, ldw, M, N, K, _chk(dbias, F32, "dbias"), float(alpha),
+              0 if ws is None else ws.data_ptr(), need, _stream())
     return dw
 
 

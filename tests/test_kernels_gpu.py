@@ -154,20 +154,23 @@ def test_gemm_nt_every_kernel_variant(dev, variant, M, N, K):
         _lib.call("ocn_set_gemm_variant", 0)
 
 
-@pytest.mark.parametrize("tv", [1, 2, 3])
+@pytest.mark.parametrize("tv", [1, 2, 3, 35])  # 35 = kernel 3 with the two-stage (workspace + reduce) epilogue (developer knob 12 = 2)
 @pytest.mark.parametrize("M,N,K", [(3000, 640, 328), (100, 264, 520), (40000, 512, 256), (9 * 50, 768, 3072), (20011, 1536, 512)])
 def test_gemm_tn_every_kernel_variant(dev, tv, M, N, K):
     from open_clip_amd import _lib, ops
     g = torch.Generator().manual_seed(tv * 10 + M)
     a = bf(torch.randn(M, N, generator=g)).to(dev)
     b = bf(torch.randn(M, K, generator=g)).to(dev)
-    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    pre = torch.randn(N, K, generator=g).to(dev) if tv == 35 else torch.zeros(N, K, device=dev)  # accumulate INTO dW
+    dw, db = pre.clone(), torch.zeros(N, device=dev)
     try:
-        _lib.call("ocn_set_gemm_variant", tv << 4)
+        _lib.call("ocn_set_gemm_variant", (3 if tv == 35 else tv) << 4)
+        _lib.call("ocn_set_tuning", 12, 2 if tv == 35 else 0)
         ops.gemm_tn_accum(a, b, dw, db)
     finally:
         _lib.call("ocn_set_gemm_variant", 0)
-    check(f"gemm_tn.v{tv}[{M}x{N}x{K}] dW", dw, a.float().t() @ b.float(), rel=1e-4)
+        _lib.call("ocn_set_tuning", 12, 0)
+    check(f"gemm_tn.v{tv}[{M}x{N}x{K}] dW", dw, pre + a.float().t() @ b.float(), rel=1e-4)
     check(f"gemm_tn.v{tv}[{M}x{N}x{K}] dbias", db, a.float().sum(0), rel=1e-4)
 
 
