@@ -88,6 +88,9 @@ int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_stream_t strea
 /* ---- casts -------------------------------------------------------------------------------------
  * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */
 int ocn_cast_f32_bf16(const float* src, void* dst, int64_t n, ocn_stream_t stream);
+/* dst = bf16(src * *scale_dev): the scalar is read on the device, so a caller that holds it in a tensor (logit_scale.exp(),
+ * loss.py:103-110) never has to synchronise the host to pass it */
+int ocn_cast_f32_bf16_scaled(const float* src, void* dst, int64_t n, const float* scale_dev, ocn_stream_t stream);
 /* dst[C,R] (bf16) = transpose(src[R,C] fp32): weight copies laid out for the NT dgrad / `@ proj` GEMMs */
 int ocn_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, ocn_stream_t stream);
 

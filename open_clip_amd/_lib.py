@@ -22,6 +22,7 @@ SIGNATURES = {
     "ocn_set_tuning": [_i, _i],
     "ocn_debug_occupy": [_i, _i, _p, _p],
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
+    "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
     "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],

@@ -81,9 +81,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const unsigned rd_addr = stg + rd_row * 128 + ((rd_chunk ^ rd_row) << 4);  // + it * 1024 for rows it*8 + rd_row
     constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_BIAS_GELU);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
-    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m0, a.M, a.ldc, OUT_F32 ? 4 : 2);
-    const __amdgpu_buffer_rsrc_t r_aux = tile_rsrc(a.aux, m0, a.M, a.ldc, 2);
-    const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, a.M, a.ldc, 4);
+    // developer knobs 32 / 128: zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued but the
+    // bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
+    const int m_st = (a.ablate & 32) ? 0 : a.M, m_ld = (a.ablate & 128) ? 0 : a.M;
+    const bool aux_is_out = (EPI == OCN_EPI_BIAS_GELU);
+    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m0, m_st, a.ldc, OUT_F32 ? 4 : 2);
+    const __amdgpu_buffer_rsrc_t r_aux = tile_rsrc(a.aux, m0, aux_is_out ? m_st : m_ld, a.ldc, 2);
+    const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 4);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
     // Bias is fetched ONCE, before any store of this tile is issued (a later load would have to wait behind the stores):
     // bf16-staged epilogues add it in the accumulator layout (before rounding), fp32-staged ones after the transpose.

@@ -15,6 +15,18 @@ __global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ ds
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f2bf(src[n4 * 4 + threadIdx.x]);
 }
 
+// dst = bf16(src * *scale): the scale stays on the device (logit_scale.exp() of the loss, loss.py:103-110 `logit_scale * image_features`)
+__global__ void cast_scaled_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long n, const float* __restrict__ scale) {
+    const float s = *scale;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(src + i * 4);
+        bf16x4 o = {f2bf(v[0] * s), f2bf(v[1] * s), f2bf(v[2] * s), f2bf(v[3] * s)};
+        *(bf16x4*)(dst + i * 4) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f2bf(src[n4 * 4 + threadIdx.x] * s);
+}
+
 // dst[C,R] = src[R,C]^T, 64x64 tiles through LDS (both sides coalesced)
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C) {
     __shared__ float tile[64][65];
@@ -216,6 +228,14 @@ extern "C" int ocn_cast_f32_bf16(const float* src, void* dst, int64_t n, ocn_str
     OCN_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "ocn_cast_f32_bf16: misaligned");
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (long)n);
     OCN_CHECK_LAUNCH("ocn_cast_f32_bf16");
+    return OCN_OK;
+}
+
+extern "C" int ocn_cast_f32_bf16_scaled(const float* src, void* dst, int64_t n, const float* scale_dev, ocn_stream_t stream) {
+    OCN_CHECK_ARG(src && dst && n > 0 && scale_dev, "ocn_cast_f32_bf16_scaled: bad arguments");
+    OCN_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "ocn_cast_f32_bf16_scaled: misaligned");
+    hipLaunchKernelGGL(cast_scaled_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (long)n, scale_dev);
+    OCN_CHECK_LAUNCH("ocn_cast_f32_bf16_scaled");
     return OCN_OK;
 }
 

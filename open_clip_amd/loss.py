@@ -24,14 +24,16 @@ def _round_up(a, b):
     return (a + b - 1) // b * b
 
 
-def _bf16_rows(x, kpad=None):
-    """fp32 [R,E] -> bf16 [R,E] (E % 64 == 0 for the hot configs; zero-pad K otherwise)"""
+def _bf16_rows(x, scale=None):
+    """fp32 [R,E] -> bf16 [R,E] (times the 1-element device tensor ``scale`` when given); E % 64 == 0 for the hot
+    configs, zero-padded K otherwise"""
     R, E = x.shape
     Ep = _round_up(E, 64)
     if Ep == E:
-        return ops.cast_bf16(x.contiguous())
+        x = x.contiguous()
+        return ops.cast_bf16(x) if scale is None else ops.cast_bf16_scaled(x, scale)
     out = torch.zeros(R, Ep, dtype=BF16, device=x.device)
-    out[:, :E].copy_(x)
+    out[:, :E].copy_(x if scale is None else x * scale)
     return out
 
 
@@ -59,52 +61,64 @@ def _reduce_scatter_sum(out, inp):
 
 
 class _PairTerm:
-    """One logits matrix  L = s * X @ Y^T (+ bias)  [R, N]  and what hangs off it."""
+    """One logits matrix  L = (s X) @ Y^T (+ bias)  [R, N]  and what hangs off it.
+
+    ``scale`` is a 1-element fp32 DEVICE tensor: the host never reads logit_scale (no synchronisation in the middle of the
+    step).  It is folded into the bf16 cast of X -- `logit_scale * image_features @ text_features.T` (loss.py:103-110)
+    evaluates (s X) first, too -- so the logits GEMM, the G^T (s X) product and the kernels take no scalar from the host;
+    the two places where s multiplies / divides a small result are 1-element device ops."""
 
     def __init__(self, X, Y, scale):
-        self.X, self.Y, self.s = X, Y, float(scale)
+        self.X, self.Y, self.s = X, Y, scale
         self.R, self.N, self.E = X.shape[0], Y.shape[0], X.shape[1]
-        self.x16, self.y16 = _bf16_rows(X), _bf16_rows(Y)
+        self.xs16, self.y16 = _bf16_rows(X, scale), _bf16_rows(Y)
         self.ldg = _round_up(self.N, 64)
         self.logits = torch.empty(self.R, _round_up(self.N, 4), dtype=F32, device=X.device)[:, :self.N]
         self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
 
     def compute_logits(self, bias=None):
-        bvec = None if bias is None else torch.full((self.N,), float(bias), dtype=F32, device=self.X.device)
-        ops.gemm_nt(ops.EPI_F32, self.x16, self.y16, self.logits, bias=bvec, alpha=self.s)  # bias fused in the epilogue
+        """``bias``: None or a 1-element device tensor (SigLIP's logit_bias), broadcast to the epilogue's bias vector"""
+        bvec = None if bias is None else bias.detach().reshape(1).to(F32).expand(self.N).contiguous()
+        ops.gemm_nt(ops.EPI_F32, self.xs16, self.y16, self.logits, bias=bvec)  # bias fused in the epilogue
         return self
 
     def softmax_ce(self, label_offset, loss_scale, grad_scale, acc):
-        """rows' CE against arange+offset -> acc[0] += loss, acc[1] += d/dscale; fills G"""
-        ops.softmax_ce_rows(self.logits, self.G, self.N, label_offset, loss_scale, grad_scale, 1.0 / self.s, acc[0:1], acc[1:2])
+        """rows' CE against arange+offset -> acc[0] += loss, acc[1] += sum(G * logits) (= s * d/dscale); fills G"""
+        ops.softmax_ce_rows(self.logits, self.G, self.N, label_offset, loss_scale, grad_scale, 1.0, acc[0:1], acc[1:2])
 
-    def siglip(self, label_offset, negative_only, bias, loss_scale, grad_scale, acc):
-        ops.siglip_rows(self.logits, self.G, self.N, label_offset, negative_only, bias, loss_scale, grad_scale, 1.0 / self.s,
+    def siglip(self, label_offset, negative_only, loss_scale, grad_scale, acc):
+        """acc[0] += loss, acc[1] += sum(G * logits) (bias included: the caller subtracts bias * acc[2]), acc[2] += sum(G)"""
+        ops.siglip_rows(self.logits, self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
                         acc[0:1], acc[1:2], acc[2:3])
 
     def dX(self):
         """s * G @ Y  -> [R, E] fp32"""
         yt = _bf16_transposed(self.Y, self.ldg)
         out = torch.empty(self.R, self.E, dtype=F32, device=self.X.device)
-        return ops.gemm_nt(ops.EPI_F32, self.G, yt, out, alpha=self.s)
+        return ops.gemm_nt(ops.EPI_F32, self.G, yt, out).mul_(self.s)
 
     def dY(self):
-        """s * G^T @ X -> [N, E] fp32"""
+        """G^T @ (s X) -> [N, E] fp32"""
         Np = _round_up(self.N, 8)
-        Ep = self.x16.shape[1]
+        Ep = self.xs16.shape[1]
         out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
-        ops.gemm_tn_accum(self.G[:, :Np], self.x16, out, alpha=self.s)
+        ops.gemm_tn_accum(self.G[:, :Np], self.xs16, out)
         return out[:self.N, :self.E]
+
+
+def _device_scalar(t, dev):
+    """1-element fp32 device tensor with the value of ``t`` (a 0-d parameter / tensor); no host read"""
+    return t.detach().to(device=dev, dtype=F32).reshape(1)
 
 
 class _ClipLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
-        s = float(logit_scale.detach())
         dev = I.device
+        s = _device_scalar(logit_scale, dev)  # stays on the device: no host synchronisation inside the step
         B, E = I.shape
-        acc = torch.zeros(2, dtype=F32, device=dev)  # [loss_sum, dscale_sum]
+        acc = torch.zeros(2, dtype=F32, device=dev)  # [loss_sum, sum(G * logits) = s * dscale]
         if world_size > 1:
             packed = torch.cat([I, T], dim=1)
             allp = torch.empty(world_size * B, 2 * E, dtype=F32, device=dev)
@@ -166,6 +180,7 @@ class _ClipLossFn(torch.autograd.Function):
             else:                                   # loss.py:47-50: only the local slot carries gradient
                 dI, dT = dI_all[lo:hi].contiguous(), dT_all[lo:hi].contiguous()
                 d_all = None
+        acc[1:2].div_(s)  # d loss / d logit_scale = sum(G * logits) / s
         ctx.save_for_backward(dI, dT, acc, d_all)
         ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype)
         return acc[0].clone()
@@ -198,8 +213,8 @@ class NativeClipLoss(nn.Module):
         self.row_sharded = row_sharded
 
     def forward(self, image_features, text_features, logit_scale, logit_bias=None, output_dict=False):
-        if logit_bias is not None:
-            raise NotImplementedError("NativeClipLoss: a logit_bias shifts every logit of a softmax row equally; use NativeSigLipLoss")
+        # loss.py:111-113 adds logit_bias to both logit matrices; a constant added to every logit of a row changes neither the
+        # softmax nor the cross-entropy, so it is accepted and contributes nothing (its gradient is exactly zero there as well)
         loss = _ClipLossFn.apply(image_features, text_features, logit_scale, self.local_loss, self.gather_with_grad,
                                  self.rank, self.world_size, self.row_sharded)
         return {"contrastive_loss": loss} if output_dict else loss
@@ -209,8 +224,8 @@ class _SigLipLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
-        s, b = float(logit_scale.detach()), float(logit_bias.detach())
         dev = I.device
+        s, b = _device_scalar(logit_scale, dev), _device_scalar(logit_bias, dev)
         B, E = I.shape
         acc = torch.zeros(3, dtype=F32, device=dev)  # loss, dscale, dbias
         if world_size > 1:
@@ -221,7 +236,8 @@ class _SigLipLossFn(torch.autograd.Function):
         # loss.py:406-489: local chunk with positives on the diagonal, every other rank's chunk negative-only.
         # One logits matrix [B, W*B]; the positive diagonal sits at column offset B*rank.
         term = PairTerm(I, T_all, s).compute_logits(bias=b)
-        term.siglip(B * rank, 0, b, 1.0 / B, 1.0 / B, acc)
+        term.siglip(B * rank, 0, 1.0 / B, 1.0 / B, acc)
+        acc[1:2].sub_(b * acc[2:3]).div_(s)  # d/dscale = sum(G * (logits - bias)) / s
         dI = term.dX()
         dT_all = term.dY().contiguous()
         ctx.save_for_backward(dI, dT_all, acc)

@@ -85,6 +85,13 @@ def cast_bf16(src, out=None):
     return out
 
 
+def cast_bf16_scaled(src, scale, out=None):
+    """bf16(src * scale) with ``scale`` a 1-element fp32 DEVICE tensor (no host read of its value)"""
+    out = empty(src.shape, BF16, src) if out is None else out
+    _lib.call("ocn_cast_f32_bf16_scaled", _chk(src, F32, "src"), _chk(out, BF16, "out"), src.numel(), _chk(scale, F32, "scale"), _stream())
+    return out
+
+
 def cast_transpose_bf16(src, out=None):
     R, C = src.shape
     out = empty((C, R), BF16, src) if out is None else out

@@ -85,6 +85,13 @@ class NativeAdamW(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plan = self._plan_key = None  # the moments are new tensors: rebuild the device table on the next step
+        for st in self.state.values():      # torch stores `step` as a tensor in its own AdamW checkpoints: accept both
+            if torch.is_tensor(st.get("step")):
+                st["step"] = int(st["step"].item())
+
     # ---- fused path ---------------------------------------------------------------------------------------------------
     def _copies_of(self, p):
         n = t = None
@@ -135,7 +142,7 @@ class NativeAdamW(torch.optim.Optimizer):
         active = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not active:
             return loss
-        key = tuple((id(p),) + tuple(map(id, self._copies_of(p))) if p.ndim in (2, 4) else (id(p),) for _, p in active)
+        key = tuple((id(p), tuple(p.shape)) + (tuple(map(id, self._copies_of(p))) if p.ndim in (2, 4) else ()) for _, p in active)
         if key != self._plan_key:
             self._plan, self._plan_key = self._build_plan(active), key
         plan = self._plan
@@ -150,12 +157,19 @@ class NativeAdamW(torch.optim.Optimizer):
                 raise RuntimeError("NativeAdamW (fused): all param groups must share betas and eps")
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             grads.append(g)
-            st = self.state[p]
+            st = self._state_of(p)
             st["step"] += 1
             e = ent[i]
-            e["g"] = g.data_ptr()
-            if g.data_ptr() % 16 and e["mode"] == 0:
-                e["mode"] = 2
+            # every pointer of the record is re-read every step: load_state_dict(), model.to(), `p.data = ...` replace the
+            # parameter / moment tensors behind an unchanged id(p), and a cached address would then update freed memory
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            if not (m.is_contiguous() and v.is_contiguous() and p.is_contiguous()):
+                raise RuntimeError("NativeAdamW (fused): parameters and their moments must be contiguous")
+            if m.device != p.device or m.dtype != torch.float32 or v.dtype != torch.float32:
+                st["exp_avg"], st["exp_avg_sq"] = m, v = m.to(p.device, torch.float32), v.to(p.device, torch.float32)
+            e["w"], e["m"], e["v"], e["g"] = p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr()
+            if e["mode"] != 1:
+                e["mode"] = 0 if (p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and m.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0) else 2
             e["lr"], e["wd"] = group["lr"], group["weight_decay"]
             e["bc1"] = 1.0 - b1 ** st["step"]
             e["bc2_sqrt"] = (1.0 - b2 ** st["step"]) ** 0.5

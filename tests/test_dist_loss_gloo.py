@@ -19,11 +19,11 @@ class CpuPairTerm:
     """test double with the interface of open_clip_amd.loss._PairTerm"""
 
     def __init__(self, X, Y, scale):
-        self.X, self.Y, self.s = X, Y, float(scale)
+        self.X, self.Y, self.s = X, Y, scale  # scale: 1-element tensor, as in the product (never read on the host)
         self.R, self.N, self.E = X.shape[0], Y.shape[0], X.shape[1]
 
     def compute_logits(self, bias=None):
-        self.logits = self.s * self.X @ self.Y.t() + (0.0 if bias is None else bias)
+        self.logits = (self.s * self.X) @ self.Y.t() + (0.0 if bias is None else bias.detach())
         return self
 
     def softmax_ce(self, label_offset, loss_scale, grad_scale, acc):
@@ -34,23 +34,23 @@ class CpuPairTerm:
         onehot = torch.zeros_like(p)
         onehot[torch.arange(self.R), lab] = 1
         self.G = (p - onehot) * grad_scale
-        acc[1] += (self.G * self.logits).sum() / self.s
+        acc[1] += (self.G * self.logits).sum()
 
-    def siglip(self, label_offset, negative_only, bias, loss_scale, grad_scale, acc):
+    def siglip(self, label_offset, negative_only, loss_scale, grad_scale, acc):
         lab = -torch.ones_like(self.logits)
         if not negative_only:
             lab[torch.arange(self.R), torch.arange(self.R) + label_offset] = 1
         z = lab * self.logits
         acc[0] += (-torch.nn.functional.logsigmoid(z)).sum() * loss_scale
         self.G = -lab * torch.sigmoid(-z) * grad_scale
-        acc[1] += (self.G * (self.logits - bias)).sum() / self.s
+        acc[1] += (self.G * self.logits).sum()
         acc[2] += self.G.sum()
 
     def dX(self):
         return self.s * self.G @ self.Y
 
     def dY(self):
-        return self.s * self.G.t() @ self.X
+        return self.G.t() @ (self.s * self.X)
 
 
 def _worker(rank, world, port, q):

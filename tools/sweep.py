@@ -229,6 +229,32 @@ def stagger_sweep():
     _lib.call("ocn_set_gemm_variant", 0)
 
 
+def epi_ablation_sweep():
+    """what the epilogue of the persistent NT kernel costs on top of the main loop: developer knobs 32 (stores dropped by a
+    zero-sized descriptor), 128 (epilogue operand loads dropped), 1 (GELU arithmetic skipped) -- the upper bound of what hiding
+    the epilogue under the next tile's main loop can buy (results of the ablated runs are wrong by construction)"""
+    cases = [("img qkv", Mi, 2304, 768, [0]), ("img da", Mi, 768, 768, [0]), ("img fc", Mi, 3072, 768, [0, 1, 3]), ("img out", Mi, 768, 768, [2]),
+             ("img proj", Mi, 768, 3072, [2]), ("txt fc", Mt, 2048, 512, [0, 1, 3]), ("txt out", Mt, 512, 512, [2]), ("txt proj", Mt, 512, 2048, [2])]
+    for name, M, N, K, epis in cases:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
+        bias = torch.randn(N, device=dev)
+        for epi in epis:
+            f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
+            out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+            resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
+            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            row = []
+            for mask, tag in ((0, "full"), (32, "-stores"), (32 | 128, "-stores-loads"), (32 | 128 | 1, "-stores-loads-valu"), (0, "full")):
+                _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
+                ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
+                row.append(f"{tag} {ms:.3f} ms ({2.0 * M * N * K / ms / 1e9:5.0f})")
+            print(f"{name:9s} epi {epi}: " + " | ".join(row), flush=True)
+            del out, resid, aux
+        del a, b
+    _lib.call("ocn_set_gemm_variant", 0)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "attn"):
@@ -247,3 +273,5 @@ if __name__ == "__main__":
         attn_wpe_sweep()
     if what in ("all", "tn"):
         tn_sweep()
+    if what in ("all", "epiabl"):
+        epi_ablation_sweep()
