@@ -32,6 +32,18 @@ def parse():
     ap.add_argument("--model", default="ViT-B-32")
     ap.add_argument("--local-batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true", help="skip the plain PyTorch-ROCm eager step timed beside the native one (N=1)")
+    ap.add_argument("--eager-batch", type=int, default=1024, help="batch of the eager baseline (bounded: eager autograd keeps ~2x the activations)")
+    ap.add_argument("--accum-freq", type=int, default=1, help="reference --accum-freq semantics (train.py:236-311): F micro-batches of "
+                    "--local-batch per optimizer step (features cached under no_grad, every micro-batch re-run with gradient against the "
+                    "concatenation) -> global batch = local_batch * F * N; --accum-freq 8 is the metric's gbs=32768 on ONE GPU")
+    ap.add_argument("--h2d", action="store_true", help="feed every step from pinned HOST memory: uint8 [B,H,W,3] pixels + tokens, double-buffered "
+                    "async copies on a copy stream, normalisation inside the patch kernel (open_clip_amd/input_pipeline.py); the copies are "
+                    "inside the timed region")
+    ap.add_argument("--data-ranks", type=int, default=1, help="developer: with one process, use the concatenation of the batches R ranks would "
+                    "get (what a world_size-R run sees as its global batch; tests/test_bench_gpu.py)")
+    ap.add_argument("--lr", type=float, default=5e-4)
+    ap.add_argument("--lr-warmup-steps", type=int, default=10000, help="linear warm-up as the reference schedules it (params.py:288, scheduler.py:6-15)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
@@ -87,8 +99,21 @@ class GemmTimer:
         return out
 
 
-def cpu_baseline(model_name, seconds=20.0):
-    """CPU oracle (port of the reference hot path) fwd+bwd+AdamW at the reference's CPU config (bs 32, fp32)."""
+def _reference_cpu_record():
+    """the reference's own train_one_epoch timed in the build container (oracle/ref_cpu_baseline.py; the GPU box has no /root/reference)"""
+    path = os.path.join(ROOT, "profiles", "r02_reference_cpu_train_one_epoch.json")
+    if not os.path.exists(path):
+        return None
+    r = json.load(open(path))
+    return {"value": r["pairs_per_s"], "unit": "pairs/s", "kind": "reference", "cores": r["torch_threads"], "nproc": r["nproc"], "where": r["where"],
+            "what": r["what"], "oracle_port_same_process_pairs_per_s": r["oracle_port_same_process"]["pairs_per_s"]}
+
+
+def cpu_baseline(model_name, seconds=24.0):
+    """CPU oracle (port of the reference hot path) fwd+bwd+AdamW at the reference's CPU config (bs 32, fp32) on this box's host cores.
+    The thread count is chosen by a short sweep (one step each; batch 32 does not scale to every core of a large host), then a bounded
+    sample is timed at the best setting.  The reference's own loop cannot run here; its number from the build container, with the
+    port timed beside it there, is attached (``reference_in_build_container``)."""
     from oracle import clip_oracle as O
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.synth import init_state_dict, synthetic_batch
@@ -99,21 +124,54 @@ def cpu_baseline(model_name, seconds=20.0):
     params = {k: v.clone() for k, v in state.items()}
     plist = [torch.nn.Parameter(v) for v in params.values()]
     opt = torch.optim.AdamW(plist, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2)
-    times = []
-    t_end = time.time() + seconds
-    while time.time() < t_end or len(times) < 2:
+
+    def one():
         t0 = time.time()
         outs, grads = O.train_forward_backward(batch["image"], batch["text"], {k: p.detach() for k, p in zip(params, plist)}, cfg)
         for p, k in zip(plist, params):
             p.grad = grads[k]
         opt.step()
-        times.append(time.time() - t0)
-        if len(times) >= 12:
+        return time.time() - t0
+
+    ncpu = os.cpu_count() or 1
+    t_start = time.time()
+    one()  # first touch (allocator, thread pool)
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        one()
+        sweep[th] = round(one(), 3)
+        if time.time() - t_start > seconds * 0.6:
             break
-    warm = sorted(times[1:])
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = []
+    while (time.time() - t_start < seconds or len(times) < 2) and len(times) < 8:
+        times.append(one())
+    warm = sorted(times)
     med = warm[len(warm) // 2]
-    return {"value": bs / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} steps of CPU-oracle fwd+bwd+AdamW, {model_name} fp32, batch {bs}; median of warm steps ({med:.2f} s/step)"}
+    rec = {"value": round(bs / med, 2), "unit": "pairs/s", "cores": best, "host_cores": ncpu, "kind": "port",
+           "sample": f"{len(times)} steps of CPU-oracle fwd+bwd+AdamW, {model_name} fp32, batch {bs}, {best} threads (sweep s/step: {sweep}); median {med:.2f} s/step"}
+    ref = _reference_cpu_record()
+    if ref is not None:
+        rec["reference_in_build_container"] = ref
+    return rec
+
+
+def torch_eager_baseline(model_name, batch_size, dev):
+    """the same training step as plain PyTorch-ROCm eager ops under bf16 autocast on this GPU (oracle/torch_eager.py)"""
+    from oracle import torch_eager
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.synth import init_state_dict, synthetic_batch
+    cfg = get_model_config(model_name)
+    batch = synthetic_batch(cfg, batch_size, seed=1234, device=dev)
+    torch.cuda.reset_peak_memory_stats()
+    sec, loss, peak = torch_eager.time_step(cfg, init_state_dict(cfg, seed=0), batch, steps=4, warmup=2)
+    return {"value": round(batch_size / sec, 1), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 2), "batch": batch_size, "final_loss": round(loss, 4),
+            "peak_hbm_gb": round(peak / 1e9, 1),
+            "what": "same step (ViT tower + text tower + ClipLoss + backward + torch.optim.AdamW + clamp) as plain PyTorch-ROCm eager ops under "
+                    "torch.amp.autocast(bf16): F.linear / F.scaled_dot_product_attention / F.layer_norm / F.gelu / F.cross_entropy on this GPU "
+                    "(oracle/torch_eager.py; the reference itself is not on the GPU box)"}
 
 
 def main():
@@ -156,14 +214,32 @@ def main():
     if args.grad_checkpointing:
         model.set_grad_checkpointing(True)
     B = args.local_batch
-    batch = synthetic_batch(cfg, B, seed=1234, rank=rank, device=dev)
+    F_ACC = max(1, args.accum_freq)
+    if args.data_ranks > 1:
+        assert world == 1
+        parts = [[synthetic_batch(cfg, B, seed=1234 + 1000 * j, rank=r, device=dev) for r in range(args.data_ranks)] for j in range(F_ACC)]
+        micro = [{k: torch.cat([p[k] for p in ps]) for k in ("image", "text")} for ps in parts]
+        B = B * args.data_ranks
+    else:
+        micro = [synthetic_batch(cfg, B, seed=1234 + 1000 * j, rank=rank, device=dev) for j in range(F_ACC)]
+    batch = micro[0]
+    pipe = None
+    if args.h2d:
+        # decoded pixels as a loader hands them over: uint8 [B,H,W,3] in pinned host memory (synthetic; a pool of 2 batches is cycled)
+        from open_clip_amd.input_pipeline import DeviceBatchPipeline
+        S = cfg["vision_cfg"]["image_size"]
+        gh = torch.Generator().manual_seed(99 + rank)
+        host_pool = [(torch.randint(0, 256, (B, S, S, 3), generator=gh, dtype=torch.uint8).pin_memory(), micro[j % F_ACC]["text"].cpu().pin_memory())
+                     for j in range(2)]
+        pipe = DeviceBatchPipeline(dev, (B, S, S, 3), (B, cfg["text_cfg"]["context_length"]), depth=max(2, F_ACC + 1))
+        pipe.submit(*host_pool[0])
     if args.siglip:
         from open_clip_amd.loss import NativeSigLipLoss
         loss_fn = NativeSigLipLoss(rank=rank, world_size=world)
     else:
         loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
                                  row_sharded=(world > 1 and not args.naive_global_loss))
-    opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
+    opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=args.lr, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=128, gradient_as_bucket_view=True)
@@ -172,14 +248,53 @@ def main():
     if not args.no_roofline:
         timer.install()
 
+    step_no = [0]
+
+    def micro_batches():
+        """device batches of this optimizer step; with --h2d each one arrives from pinned host memory while the previous one computes"""
+        for j in range(F_ACC):
+            if pipe is None:
+                yield micro[j]
+            else:
+                b = pipe.next()
+                pipe.submit(*host_pool[(step_no[0] * F_ACC + j + 1) % 2])  # next batch's copy runs under this batch's compute
+                yield b
+
     def step():
+        # linear warm-up of the reference's schedule (scheduler.py:6-15: lr * (step + 1) / warmup_length)
+        lr_t = args.lr * min(1.0, (step_no[0] + 1) / max(1, args.lr_warmup_steps))
+        for g in opt.param_groups:
+            g["lr"] = lr_t
         opt.zero_grad(set_to_none=True)
-        out = net(image=batch["image"], text=batch["text"])
-        loss = loss_fn(**out)
-        loss.backward()
+        if F_ACC == 1:
+            b = next(iter(micro_batches()))
+            out = net(image=b["image"], text=b["text"])
+            loss = loss_fn(**out)
+            loss.backward()
+            if pipe is not None:
+                pipe.release(b)
+        else:
+            # train.py:236-311: features of every micro-batch under no_grad, then every micro-batch again with gradient, the loss taken
+            # over the concatenation (cached features stand in for the other micro-batches)
+            held = list(micro_batches())
+            feats = {"image_features": [], "text_features": []}
+            with torch.no_grad():
+                for b in held:
+                    o = net(image=b["image"], text=b["text"])
+                    for k in feats:
+                        feats[k].append(o[k])
+            for j, b in enumerate(held):
+                o = net(image=b["image"], text=b["text"])
+                inputs = {k: torch.cat(feats[k][:j] + [o[k]] + feats[k][j + 1:]) for k in feats}
+                extra_in = {"logit_bias": o["logit_bias"]} if "logit_bias" in o else {}
+                loss = loss_fn(**inputs, logit_scale=o["logit_scale"], **extra_in)
+                loss.backward()
+                if pipe is not None:
+                    pipe.release(b)
         opt.step()
         with torch.no_grad():
             model.logit_scale.clamp_(0, math.log(100))  # image_text_task.py:91-101
+        step_no[0] += 1
         return loss
 
     def barrier():
@@ -208,18 +323,21 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = B * world / (elapsed / args.steps)
-        flops_pair = 3 * FWD_GFLOP_PER_PAIR.get(args.model, 0.0) * (4 / 3 if args.grad_checkpointing else 1.0)
+        value = B * F_ACC * world / (elapsed / args.steps)
+        # forward passes per pair: 1 (+1 recompute with grad checkpointing) (+1 no_grad feature pass with accumulation) + 2 for the backward
+        flops_pair = FWD_GFLOP_PER_PAIR.get(args.model, 0.0) * (3 + (1 if args.grad_checkpointing else 0) + (1 if F_ACC > 1 else 0))
         line = {
             "metric": ("image-text pairs/sec (whole node), ViT-B-32 gbs=32768 at 1/2/4/8 GPUs" if args.model == "ViT-B-32" and not args.siglip
                        else f"image-text pairs/sec (whole node), {args.model}{' SigLIP' if args.siglip else ''}"), "value": round(value, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} {'SigLIPTask' if args.siglip else 'CLIPTask'}-equivalent train step (fwd+{'SigLipLoss' if args.siglip else 'ClipLoss'}+bwd+AdamW+clamp), amp_bf16 policy, "
-                                   f"local_bs={B}, global_bs={B * world}, "
+                                   f"local_bs={B}, " + (f"accum_freq={F_ACC} (train.py:236-311), " if F_ACC > 1 else "") + f"global_bs={B * F_ACC * world}, "
+                                   + ("inputs from pinned host memory every step (uint8 pixels, async double-buffered H2D inside the timed region), " if args.h2d else "")
                                    + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
                                       if world > 1 else "world_size 1 (no all-gather)"),
-                       "model": args.model, "global_batch": B * world, "local_batch": B, "parallelism": f"dp{world}",
+                       "model": args.model, "global_batch": B * F_ACC * world, "local_batch": B, "accum_freq": F_ACC, "parallelism": f"dp{world}",
+                       "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             "step_model_tflops_per_gpu": round(value / world * flops_pair / 1e3, 1),
             "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated() / 1e9, 1),
@@ -243,6 +361,14 @@ def main():
                                                            "runs at ~1.2 PFLOP/s (profiles/r01_gemm_shapes.txt, OCN_WGRAD_STREAM=0)"},
                                 "event_timed_steps": timed_steps,
                                 "gemm_share_of_step": round((nt["ms"] + tn["ms"]) / (elapsed * 1e3 * timed_steps / args.steps), 3)}
+        if world == 1 and not args.no_eager_baseline and not args.siglip:
+            micro.clear()
+            torch.cuda.empty_cache()
+            try:
+                line["torch_eager_baseline"] = torch_eager_baseline(args.model, min(args.eager_batch, B), dev)
+                line["torch_eager_baseline"]["native_over_eager"] = round(value / line["torch_eager_baseline"]["value"], 2)
+            except Exception as e:  # the baseline must never take the bench line down with it
+                line["torch_eager_baseline"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,49 @@
+"""bench.py's own code paths on the MI355X at a miniature size (the model 'small-test', a few steps): the world_size-2 path -- two
+ranks on the one GPU of the test box over gloo (RCCL refuses two ranks on one device), DistributedDataParallel + the row-sharded
+global ClipLoss -- must report the same loss as one process on the concatenation of the two ranks' batches (every rank evaluates the
+FULL-batch loss in this mode, and Adam is invariant to the 1/W that DDP's mean puts on the gradients); the gradient-accumulation
+mode (--accum-freq, train.py:236-311) and the host-fed mode (--h2d) run and report what they did."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--model", "small-test", "--local-batch", "8", "--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--no-eager-baseline", "--no-roofline",
+          "--lr", "1e-3", "--lr-warmup-steps", "1"]
+
+
+def _bench(extra, nproc=1, env=None):
+    e = dict(os.environ, **(env or {}))
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29741",
+               os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + COMMON + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_world2_reports_the_full_batch_loss():
+    two = _bench(["--dist-backend", "gloo"], nproc=2, env={"OCN_BENCH_ONE_DEVICE": "1"})
+    one = _bench(["--data-ranks", "2"])
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 16 and one["config"]["global_batch"] == 16
+    assert "row-sharded" in two["config"]["workload"]
+    assert abs(two["config"]["final_loss"] - one["config"]["final_loss"]) < 3e-2, (two["config"]["final_loss"], one["config"]["final_loss"])
+
+
+def test_bench_accumulation_and_host_fed_modes():
+    acc = _bench(["--accum-freq", "2"])
+    assert acc["config"]["accum_freq"] == 2 and acc["config"]["global_batch"] == 16 and "accum_freq=2" in acc["config"]["workload"]
+    import math
+    assert math.isfinite(acc["config"]["final_loss"]) and acc["value"] > 0
+    h2d = _bench(["--h2d"])
+    assert h2d["config"]["input"] == "host_uint8_h2d" and math.isfinite(h2d["config"]["final_loss"]) and h2d["value"] > 0
+    both = _bench(["--h2d", "--accum-freq", "2"])
+    assert both["config"]["accum_freq"] == 2 and math.isfinite(both["config"]["final_loss"])

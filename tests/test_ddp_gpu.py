@@ -37,21 +37,26 @@ def _worker(rank, port, mode, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     from open_clip_amd.configs import get_model_config
-    from open_clip_amd.loss import NativeClipLoss
+    from open_clip_amd.loss import NativeClipLoss, NativeSigLipLoss
     from open_clip_amd.model import NativeCLIP
     from open_clip_amd.synth import init_state_dict, synthetic_batch
     torch.cuda.set_device(0)
     cfg = get_model_config("small-test")
-    state = init_state_dict(cfg, seed=3, perturb=True)
+    siglip = mode == "siglip"
+    state = init_state_dict(cfg, seed=3, perturb=True, siglip=siglip)
     batch = synthetic_batch(cfg, WORLD * B_LOCAL, seed=11)
-    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True)
+    extra = dict(init_logit_scale=float(np.log(10)), init_logit_bias=-10.0) if siglip else {}
+    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True, **extra)
     model.load_state_dict(state)
     model = model.cuda().train()
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=1, gradient_as_bucket_view=True)
-    kw = {"global": dict(local_loss=False, gather_with_grad=False),
-          "global_rowsharded": dict(local_loss=False, gather_with_grad=False, row_sharded=True),
-          "local_gwg": dict(local_loss=True, gather_with_grad=True)}[mode]
-    loss_fn = NativeClipLoss(rank=rank, world_size=WORLD, **kw)
+    if siglip:  # SigLIPTask's loss (siglip_task.py:35-43): every rank's images against every rank's texts, positives only locally
+        loss_fn = NativeSigLipLoss(rank=rank, world_size=WORLD)
+    else:
+        kw = {"global": dict(local_loss=False, gather_with_grad=False),
+              "global_rowsharded": dict(local_loss=False, gather_with_grad=False, row_sharded=True),
+              "local_gwg": dict(local_loss=True, gather_with_grad=True)}[mode]
+        loss_fn = NativeClipLoss(rank=rank, world_size=WORLD, **kw)
     lo, hi = rank * B_LOCAL, (rank + 1) * B_LOCAL
     losses = []
     for _ in range(2):  # two passes: the second one runs with DDP's rebuilt buckets and re-used gradient views
@@ -61,13 +66,13 @@ def _worker(rank, port, mode, outdir):
         loss.backward()
         torch.cuda.synchronize()
         losses.append(float(loss.detach()))
-    grads = {k: p.grad.detach().float().cpu().numpy() for k, p in model.named_parameters() if k in KEYS}
+    grads = {k: p.grad.detach().float().cpu().numpy() for k, p in model.named_parameters() if k in KEYS or k == "logit_bias"}
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), loss=np.array(losses), **grads)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["global", "global_rowsharded", "local_gwg"])
+@pytest.mark.parametrize("mode", ["global", "global_rowsharded", "local_gwg", "siglip"])
 def test_two_ranks_ddp_against_full_batch_oracle(mode, tmp_path):
     import torch.multiprocessing as mp
     from open_clip_amd.configs import get_model_config
@@ -76,9 +81,9 @@ def test_two_ranks_ddp_against_full_batch_oracle(mode, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(port, mode, str(tmp_path)), nprocs=WORLD, join=True)
     cfg = get_model_config("small-test")
-    state = init_state_dict(cfg, seed=3, perturb=True)
+    state = init_state_dict(cfg, seed=3, perturb=True, siglip=(mode == "siglip"))
     batch = synthetic_batch(cfg, WORLD * B_LOCAL, seed=11)
-    ref, rgrads = O.train_forward_backward(batch["image"], batch["text"], state, cfg)
+    ref, rgrads = O.train_forward_backward(batch["image"], batch["text"], state, cfg, siglip=(mode == "siglip"))
     r = [np.load(os.path.join(str(tmp_path), f"rank{i}.npz")) for i in range(WORLD)]
     for i in range(WORLD):
         assert abs(r[i]["loss"][0] - r[i]["loss"][1]) < 1e-5, "the two passes must agree (same weights, same data)"
@@ -87,15 +92,47 @@ def test_two_ranks_ddp_against_full_batch_oracle(mode, tmp_path):
             assert abs(float(r[i]["loss"][1]) - float(ref["loss"])) < 2e-2, (r[i]["loss"], float(ref["loss"]))
         gscale = 1.0 / WORLD
     else:
+        # local_loss + gather_with_grad, and SigLIP (loss.py:406-489: a rank's loss = its B images against all N texts, divided by
+        # B, NOT averaged over ranks): the MEAN of the rank losses is the single-process full-batch loss, and so is the DDP mean
+        # of the gradients (logit_scale / logit_bias included)
         assert abs(np.mean([float(x["loss"][1]) for x in r]) - float(ref["loss"])) < 2e-2
         gscale = 1.0
-    for k in KEYS:
+    for k in KEYS + (["logit_bias"] if mode == "siglip" else []):
         g0, g1 = torch.from_numpy(r[0][k]), torch.from_numpy(r[1][k])
         assert torch.equal(g0, g1), f"{k}: ranks disagree after the gradient all-reduce"
         # logit_scale: in the global mode every rank evaluates the FULL loss, so each holds the full d/ds and the DDP mean
         # leaves it unscaled (only the feature gradients are restricted to the local slice, loss.py:47-50)
-        want = rgrads[k] * (1.0 if k == "logit_scale" else gscale)
+        want = rgrads[k] * (1.0 if (k == "logit_scale" and mode.startswith("global")) else gscale)
         if mode == "global_rowsharded" and k == "logit_scale":
             pass  # every rank holds the all-reduced (full) d/ds, exactly as in the redundant evaluation
         rel = float((g0 - want).norm() / want.norm().clamp_min(1e-12))
         assert rel < 6e-2, (mode, k, rel)
+
+
+def _nccl_one_rank_worker(rank, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from open_clip_amd.loss import _reduce_scatter_sum
+    g = torch.Generator().manual_seed(5)
+    inp = torch.randn(6, 10, generator=g).cuda()
+    out = torch.empty(6, 10, device="cuda")
+    _reduce_scatter_sum(out, inp)  # the RCCL branch (dist.reduce_scatter_tensor): the one line the gloo runs cannot execute
+    packed = torch.randn(6, 8, generator=g).cuda()
+    allp = torch.empty(6, 8, device="cuda")
+    dist.all_gather_into_tensor(allp, packed)  # the packed feature all-gather of the loss forward, same process group
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(out, inp)) and bool(torch.equal(allp, packed))
+    open(os.path.join(outdir, "ok.txt"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_rccl_process_group_runs_the_loss_collectives(tmp_path):
+    """A one-rank RCCL ("nccl") process group on the test box's GPU: the collectives the distributed loss issues
+    (all_gather_into_tensor forward, reduce_scatter_tensor backward) run through RCCL itself -- with one rank they must be
+    identities.  (Two ranks cannot share a device under RCCL; the multi-rank semantics are covered over gloo above.)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(os.path.join(str(tmp_path), "ok.txt")).read() == "1"

@@ -1,0 +1,114 @@
+"""The GEMM kernels at the EXACT shapes of the bench step (ViT-B-32, local batch 4096: M = 4096*50 = 204800 image tokens,
+M = 4096*77 = 315392 text tokens), every epilogue the step uses at that shape, against fp32 torch evaluated on the GPU in row
+chunks.  These are the launches whose persistent tile walk (37-77 tiles per workgroup, banded order, start stagger) the small
+parity shapes never reach.
+
+Tolerances: fp32 outputs rel-L2 <= 2e-5 (accumulation order); bf16 outputs rel-L2 <= 2.5e-3 and every element within one bf16
+rounding of the fp32 value (|err| <= 2^-7 |ref| + abs_tol); weight gradients (fp32 atomics over up to 77 M-splits) rel-L2 <= 2e-4.
+Outputs are pre-filled with NaN so that a tile the walk never visits cannot pass."""
+import pytest
+import torch
+
+from tests.test_kernels_gpu import _report, bf, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+MI, MT = 4096 * 50, 4096 * 77
+CHUNK = 16384
+EPI_NAMES = {0: "bf16", 1: "bias+gelu", 2: "bias+resid_f32", 3: "dgelu", 4: "f32"}
+
+# (name, M, N, K, epilogue, bias?) -- forward and dgrad GEMMs of one residual block of each tower (model.py::_block_forward /
+# _BlockFn.backward; reference transformer.py:169,246,295-299,328-329)
+NT_CASES = []
+for tag, M, C in (("img", MI, 768), ("txt", MT, 512)):
+    NT_CASES += [
+        (f"{tag} qkv", M, 3 * C, C, 0, True), (f"{tag} out_proj", M, C, C, 2, True), (f"{tag} c_fc", M, 4 * C, C, 1, True),
+        (f"{tag} c_proj", M, C, 4 * C, 2, True), (f"{tag} dgelu", M, 4 * C, C, 3, False), (f"{tag} dh2", M, C, 4 * C, 0, False),
+        (f"{tag} da", M, C, C, 0, False), (f"{tag} dh1", M, C, 3 * C, 0, False),
+    ]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from open_clip_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _gelu_and_derivative(x):
+    return torch.nn.functional.gelu(x), 0.5 * (1 + torch.erf(x * 2 ** -0.5)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+
+
+@pytest.mark.parametrize("name,M,N,K,epi,with_bias", NT_CASES, ids=[c[0].replace(" ", "_") for c in NT_CASES])
+def test_gemm_nt_at_bench_shape(dev, name, M, N, K, epi, with_bias):
+    from open_clip_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + 31 * N + K + epi)
+    a = bf(torch.randn(M, K, device=dev, generator=g))
+    b = bf(torch.randn(N, K, device=dev, generator=g) * K ** -0.5)
+    bias = torch.randn(N, device=dev, generator=g) if with_bias else None
+    f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
+    out = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
+    resid = torch.randn(M, N, device=dev, generator=g) if epi == ops.EPI_BIAS_RESID_F32 else None
+    aux = None
+    if epi == ops.EPI_BIAS_GELU:
+        aux = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    elif epi == ops.EPI_DGELU:
+        aux = bf(torch.rand(M, N, device=dev, generator=g) * 1.25 - 0.125)  # the range of gelu'
+    ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux)
+    torch.cuda.synchronize()
+    worst, worst_aux, bad = 0.0, 0.0, 0
+    for r0 in range(0, M, CHUNK):
+        sl = slice(r0, min(M, r0 + CHUNK))
+        acc = a[sl].float() @ b.float().t()
+        if bias is not None:
+            acc += bias
+        ref2 = None
+        if epi == ops.EPI_BIAS_GELU:
+            ref, ref2 = _gelu_and_derivative(acc)
+        elif epi == ops.EPI_BIAS_RESID_F32:
+            ref = acc + resid[sl]
+        elif epi == ops.EPI_DGELU:
+            ref = acc * aux[sl].float()
+        else:
+            ref = acc
+        got = out[sl].float()
+        assert torch.isfinite(got).all(), f"{name}: rows {r0}.. hold non-finite values (tile never written?)"
+        worst = max(worst, rel_l2(got, ref))
+        if not f32out:
+            bad += int(((got - ref).abs() > ref.abs() * 2.0 ** -7 + 2e-3).sum())
+        if ref2 is not None:
+            got2 = aux[sl].float()
+            assert torch.isfinite(got2).all(), f"{name}: saved gelu' rows {r0}.. non-finite"
+            worst_aux = max(worst_aux, rel_l2(got2, ref2))
+            bad += int(((got2 - ref2).abs() > ref2.abs() * 2.0 ** -7 + 2e-3).sum())
+    _report(f"bench-shape gemm_nt {name:12s} [{M}x{N}x{K}] {EPI_NAMES[epi]:15s} rel_l2={worst:.3e}" + (f" aux rel_l2={worst_aux:.3e}" if epi == 1 else ""))
+    assert worst <= (2e-5 if f32out else 2.5e-3), (name, worst)
+    assert worst_aux <= 2.5e-3 and bad == 0, (name, worst_aux, bad)
+
+
+TN_CASES = []
+for tag, M, C in (("img", MI, 768), ("txt", MT, 512)):
+    TN_CASES += [(f"{tag} wgrad qkv", M, 3 * C, C), (f"{tag} wgrad out_proj", M, C, C), (f"{tag} wgrad c_fc", M, 4 * C, C), (f"{tag} wgrad c_proj", M, C, 4 * C)]
+
+
+@pytest.mark.parametrize("name,M,N,K", TN_CASES, ids=[c[0].replace(" ", "_") for c in TN_CASES])
+def test_gemm_tn_at_bench_shape(dev, name, M, N, K):
+    """dW[N,K] += A[M,N]^T B[M,K], dbias[N] += colsum(A): the weight / bias gradients of the block's four Linears"""
+    from open_clip_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + 17 * N + K)
+    a = bf(torch.randn(M, N, device=dev, generator=g))
+    b = bf(torch.randn(M, K, device=dev, generator=g))
+    pre = torch.randn(N, K, device=dev, generator=g)  # the kernel accumulates INTO dW: start from a known non-zero value
+    dw, db = pre.clone(), torch.zeros(N, device=dev)
+    ops.gemm_tn_accum(a, b, dw, db)
+    torch.cuda.synchronize()
+    ref = torch.zeros(N, K, device=dev, dtype=torch.float64)
+    refb = torch.zeros(N, device=dev, dtype=torch.float64)
+    for r0 in range(0, M, CHUNK):
+        sl = slice(r0, min(M, r0 + CHUNK))
+        ref += (a[sl].float().t() @ b[sl].float()).double()
+        refb += a[sl].float().sum(0).double()
+    e1, e2 = rel_l2(dw.double() - pre.double(), ref), rel_l2(db, refb)
+    _report(f"bench-shape gemm_tn {name:18s} dW[{N}x{K}] over M={M}: rel_l2={e1:.3e} dbias rel_l2={e2:.3e}")
+    assert torch.isfinite(dw).all() and e1 <= 2e-4 and e2 <= 2e-4, (name, e1, e2)

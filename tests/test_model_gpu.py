@@ -328,3 +328,125 @@ def test_training_steps_with_fused_optimizer_track_the_cpu_oracle():
         # move differently in any two implementations; the bound only has to catch a wrong update (error ~ the movement itself)
         bound = 0.35
         assert float(err) <= bound * float(moved) + 1e-6, (k, float(err), float(moved))
+
+
+def test_reference_train_loop_under_autocast_tracks_the_cpu_oracle():
+    """The step exactly as the reference's loop runs it on a GPU (the reference itself is not on the GPU box, so its few lines of
+    glue are restated here with their sources): batches arrive as pinned HOST tensors and go through ``prepare_batch``
+    (base_task.py:135-157: ``.to(device, non_blocking=True)``, floats keep their dtype under amp), the forward runs inside
+    ``torch.amp.autocast('cuda', dtype=torch.bfloat16)`` (precision.py:6-17, train.py:228-231), ``training_forward`` sums the
+    ``*_loss`` entries (clip_task.py:41-46), then ``backward`` OUTSIDE the autocast region, ``torch.nn.utils.clip_grad_norm_`` on
+    ``.grad`` (train.py:205-214), ``optimizer.step()`` and ``clamp_logit_scale`` (image_text_task.py:91-101).  Three steps against
+    the CPU oracle stepped with torch.optim.AdamW: per-step losses and the final parameters."""
+    import math
+    from functools import partial
+    from open_clip_amd.loss import NativeClipLoss
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
+    from oracle import clip_oracle as O
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=51, perturb=True)
+    device = torch.device("cuda:0")
+    lr, wd, clip = 2e-3, 0.2, 1.0
+    model = _build(cfg, state)
+    loss_mod = NativeClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=0, world_size=1)  # create_task's arguments
+    optimizer = NativeAdamW(param_groups_like_reference(model, wd), lr=lr, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
+    autocast = partial(torch.amp.autocast, device_type="cuda", dtype=torch.bfloat16)
+
+    def prepare_batch(batch, input_dtype=None):  # base_task.py:135-157
+        return {k: (v.to(device=device, dtype=input_dtype, non_blocking=True) if v.is_floating_point() else v.to(device=device, non_blocking=True))
+                for k, v in batch.items()}
+
+    def training_forward(batch):  # clip_task.py:41-46
+        model_out = model(image=batch["image"], text=batch["text"])
+        losses = loss_mod(**model_out, output_dict=True)
+        losses["loss"] = sum(v for k, v in losses.items() if k.endswith("_loss"))
+        return losses, {k: model_out[k] for k in ("logit_scale", "logit_bias") if k in model_out}
+
+    ref_params = {k: torch.nn.Parameter(v.clone().float()) for k, v in state.items()}
+    skip = {"positional_embedding", "visual.positional_embedding", "visual.class_embedding"}
+    ref_opt = torch.optim.AdamW([{"params": [p for k, p in ref_params.items() if p.ndim <= 1 or k in skip], "weight_decay": 0.0},
+                                 {"params": [p for k, p in ref_params.items() if not (p.ndim <= 1 or k in skip)], "weight_decay": wd}],
+                                lr=lr, betas=(0.9, 0.98), eps=1e-6)
+    for i in range(3):
+        host = {k: v.pin_memory() for k, v in synthetic_batch(cfg, 8, seed=300 + i).items()}
+        batch = prepare_batch(host)
+        optimizer.zero_grad()
+        with autocast():
+            losses, report = training_forward(batch)
+            total_loss = losses["loss"]
+        total_loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip, norm_type=2.0)
+        optimizer.step()
+        with torch.no_grad():
+            model.logit_scale.clamp_(0, math.log(100))
+        assert total_loss.dtype == torch.float32 and report["logit_scale"].dtype == torch.float32
+        outs, grads = O.train_forward_backward(host["image"], host["text"], {k: p.detach() for k, p in ref_params.items()}, cfg)
+        for k, p in ref_params.items():
+            p.grad = grads[k]
+        torch.nn.utils.clip_grad_norm_(list(ref_params.values()), clip)
+        ref_opt.step()
+        with torch.no_grad():
+            ref_params["logit_scale"].clamp_(0, math.log(100))
+        _report(f"autocast-loop[{i}]: loss {float(total_loss.detach()):.5f} oracle {float(outs['loss']):.5f}")
+        assert abs(float(total_loss.detach()) - float(outs["loss"])) <= LOSS_TOL, i
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        ref, got, start = ref_params[k].detach(), p.detach().float().cpu(), state[k].float()
+        if k.endswith("attn.in_proj_bias"):  # the K third has an exactly-zero gradient: Adam moves it by rounding noise alone
+            c = ref.numel() // 3
+            keep = torch.cat([torch.arange(0, c), torch.arange(2 * c, 3 * c)])
+            ref, got, start = ref[keep], got[keep], start[keep]
+        assert float((got - ref).norm()) <= 0.35 * float((ref - start).norm()) + 1e-6, k
+
+
+def test_vith14_siglip_full_size_against_cpu_oracle_and_loss_after_one_update():
+    """BASELINE config 5 at FULL model size (ViT-H-14 + SigLIP loss, block recompute), B = 2, against the CPU oracle: loss, features and
+    a spread of gradients.  Then ONE AdamW update at the bench's learning rate on both sides and the loss again: round 1's sanity
+    bench line ended at final_loss 178.8 after three updates (init ~10).  If the native loss after the update agrees with the
+    oracle's, that excursion is the optimizer's (lr 5e-4 from step 0 on a 1 B-parameter model, where the reference warms up over
+    10 000 steps, params.py:288) and not the kernels'."""
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
+    from oracle import clip_oracle as O
+    cfg = get_model_config("ViT-H-14")
+    state = init_state_dict(cfg, seed=5, siglip=True)
+    batch = synthetic_batch(cfg, 2, seed=29)
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    outs, grads = O.train_forward_backward(batch["image"], batch["text"], state, cfg, siglip=True)
+    model = _build(cfg, state, siglip=True)
+    model.set_grad_checkpointing(True)
+    opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
+    out, loss = _step(model, batch, siglip=True)
+    fi = float((out["image_features"].float().cpu() - outs["image_features"]).abs().max())
+    ft = float((out["text_features"].float().cpu() - outs["text_features"]).abs().max())
+    _report(f"oracle[ViT-H-14 SigLIP,B2,ckpt]: feat max_abs {fi:.3e}/{ft:.3e} loss {float(loss):.6f} vs {float(outs['loss']):.6f}")
+    assert fi <= FEAT_TOL and ft <= FEAT_TOL
+    assert abs(float(loss) - float(outs["loss"])) <= LOSS_TOL
+    gmax = max(float(v.norm()) for v in grads.values())
+    keys = ["visual.conv1.weight", "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.31.mlp.c_fc.weight",
+            "visual.transformer.resblocks.15.attn.out_proj.weight", "transformer.resblocks.0.mlp.c_proj.weight", "transformer.resblocks.23.attn.in_proj_weight",
+            "text_projection", "visual.proj", "visual.positional_embedding", "logit_scale", "logit_bias"]
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = grads[k]
+        rel = float((named[k].grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        tol = GRAD_TOL if float(ref.norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        _report(f"oracle[ViT-H-14]:   grad rel_l2={rel:.3e} |g|={float(ref.norm()):.3e} {k}")
+        assert rel <= tol, (k, rel)
+    # one update on both sides, then the loss on the same batch
+    opt.step()
+    ref_params = {k: torch.nn.Parameter(v.clone().float()) for k, v in state.items()}
+    skip = {"positional_embedding", "visual.positional_embedding", "visual.class_embedding"}
+    ref_opt = torch.optim.AdamW([{"params": [p for k, p in ref_params.items() if p.ndim <= 1 or k in skip], "weight_decay": 0.0},
+                                 {"params": [p for k, p in ref_params.items() if not (p.ndim <= 1 or k in skip)], "weight_decay": 0.2}],
+                                lr=5e-4, betas=(0.9, 0.98), eps=1e-6)
+    for k, p in ref_params.items():
+        p.grad = grads[k]
+    ref_opt.step()
+    with torch.no_grad():
+        o2 = model(image=batch["image"].cuda(), text=batch["text"].cuda())
+        from open_clip_amd.loss import NativeSigLipLoss
+        l2 = float(NativeSigLipLoss()(**o2))
+        ro = O.clip_forward(batch["image"].float(), batch["text"], {k: p.detach() for k, p in ref_params.items()}, cfg)
+        r2 = float(O.siglip_loss(ro["image_features"], [ro["text_features"]], ro["logit_scale"], ro["logit_bias"], 0))
+    _report(f"oracle[ViT-H-14]: loss after one AdamW update at lr 5e-4: native {l2:.4f} oracle {r2:.4f} (before: {float(outs['loss']):.4f})")
+    assert abs(l2 - r2) <= max(5 * LOSS_TOL, 0.03 * abs(r2))
