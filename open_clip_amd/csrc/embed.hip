@@ -63,6 +63,42 @@ __global__ void patchify_u8_kernel(const unsigned char* __restrict__ img, bf16* 
     }
 }
 
+// Fast path of the same for the decoder layout [B,H,W,3] with P % 16 == 0 (ViT-B-32 / B-16): a patch row is 3P contiguous bytes,
+// so a workgroup pulls one whole patch (P rows x 3P bytes) into LDS with 16-byte loads and writes its 3P^2 bf16 values as 16-byte
+// stores (8 consecutive k = one colour plane, one patch row, 8 consecutive pixels: bytes 3 apart in the staged row).  The generic
+// kernel above moves 2 bytes in and 4 out per thread (4096 x 224 x 224: 4 ms instead of 0.5).
+__global__ __launch_bounds__(256) void patchify_u8_hwc_kernel(const unsigned char* __restrict__ img, bf16* __restrict__ out, int H, int W, int P,
+                                                              int Kpad, long npatch, NormC nc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pix[];
+    const int gh = H / P, gw = W / P, rowb = 3 * P, n16 = P * (rowb >> 4), per_row = rowb >> 4, KP = 3 * P * P, nq = Kpad >> 3;
+    for (long patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        const int b = (int)(patch / (gh * gw)), g = (int)(patch % (gh * gw)), py = g / gw, px = g % gw;
+        const unsigned char* base = img + (((size_t)b * H + (size_t)py * P) * W + (size_t)px * P) * 3;
+        __syncthreads();  // the previous patch has been read out of LDS
+        for (int t = threadIdx.x; t < n16; t += blockDim.x) {
+            const int i = t / per_row, c16 = t - i * per_row;
+            *(uint4*)(pix + i * rowb + c16 * 16) = *(const uint4*)(base + (size_t)i * W * 3 + c16 * 16);
+        }
+        __syncthreads();
+        bf16* o = out + patch * Kpad;
+        for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+            const int k0 = q << 3;
+            bf16x8 v;
+            if (k0 >= KP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            } else {
+                const int c = k0 / (P * P), rem = k0 - c * P * P, i = rem / P, j0 = rem - i * P;
+                const unsigned char* sp = pix + i * rowb + j0 * 3 + c;
+                const float sc = nc.scale[c], sh = nc.shift[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f2bf(fmaf((float)sp[3 * e], sc, sh));
+            }
+            *(bf16x8*)(o + k0) = v;
+        }
+    }
+}
+
 // ---- class token + positional embedding (transformer.py:799-801) --------------------------------
 __global__ void embed_assemble_fwd_kernel(const float* __restrict__ po, const float* __restrict__ cls,
                                           const float* __restrict__ pos, float* __restrict__ emb, int B, int G, int C) {
@@ -274,6 +310,13 @@ extern "C" int ocn_patchify_u8(const void* image_u8, int hwc, const float* mean3
         OCN_CHECK_ARG(std3[c] > 0.f, "ocn_patchify_u8: std must be positive");
         nc.scale[c] = 1.0f / (255.0f * std3[c]);
         nc.shift[c] = -mean3[c] / std3[c];
+    }
+    if (hwc && P % 16 == 0 && Kpad % 8 == 0 && ((uintptr_t)image_u8 & 15) == 0 && ((uintptr_t)patches & 15) == 0) {
+        const long npatch = (long)B * (H / P) * (W / P);
+        hipLaunchKernelGGL(patchify_u8_hwc_kernel, dim3((unsigned)(npatch < 16384 ? npatch : 16384)), dim3(256), 3 * P * P, (hipStream_t)stream,
+                           (const unsigned char*)image_u8, (bf16*)patches, H, W, P, Kpad, npatch, nc);
+        OCN_CHECK_LAUNCH("ocn_patchify_u8");
+        return OCN_OK;
     }
     const long total = (long)B * (H / P) * (W / P) * (Kpad / 2);
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)image_u8,

@@ -52,14 +52,18 @@ class DeviceBatchPipeline:
         if self._queued == self.depth:
             raise RuntimeError("DeviceBatchPipeline: all slots are in flight; call next() / release() first")
         s = self.slots[self._w]
+        src_i, src_t = s["h_image"], s["h_text"]
         if image_host is not None:
-            hi, ht = self.staging()
-            hi.copy_(image_host)
-            ht.copy_(text_host)
+            if image_host.is_pinned() and text_host.is_pinned():
+                src_i, src_t = image_host, text_host  # already page-locked (DataLoader(pin_memory=True)): DMA straight out of it
+            else:
+                hi, ht = self.staging()
+                hi.copy_(image_host)
+                ht.copy_(text_host)
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(s["free"])  # the forward that read this slot last has consumed it
-            s["image"].copy_(s["h_image"], non_blocking=True)
-            s["text"].copy_(s["h_text"], non_blocking=True)
+            s["image"].copy_(src_i, non_blocking=True)
+            s["text"].copy_(src_t, non_blocking=True)
             s["ready"].record(self.copy_stream)
             s["host_done"] = s["ready"]
         self._w = (self._w + 1) % self.depth

@@ -360,7 +360,7 @@ def test_vision_embed_kernels(dev, B, H, P, width):
     assert torch.equal(dpatch, d3[:, 1:].reshape(B * G, width).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("H,P", [(64, 32), (28, 14)])
+@pytest.mark.parametrize("H,P", [(64, 32), (28, 14), (48, 16), (224, 32)])
 def test_patchify_uint8_input_fuses_totensor_normalize(dev, H, P):
     """8f-4: uint8 pixels in either layout -> the same bf16 patch matrix as ToTensor + Normalize (constants.py:1-2)
     followed by the float path (one bf16 rounding of a value computed with a fused multiply-add: <= 1 bf16 ulp apart)."""
