@@ -178,6 +178,14 @@ int ocn_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float
 int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, float loss_scale,
                         float grad_scale, float inv_logit_scale, float* loss_sum, float* dscale_sum,
                         ocn_stream_t stream);
+/* The same cross-entropy WITHOUT materialised logits (loss.py:103-110 + :136-139 for a [R, N] block of logits_per_image / _per_text;
+ * the row-sharded global loss of 8 GPUs has R = 4096, N = 32768): X bf16 [R, E] (already times logit_scale), Y bf16 [N, E]; two passes
+ * of the MFMA GEMM consume the fp32 logits tile in registers (online log-sum-exp, then G = (softmax - onehot) * grad_scale as bf16
+ * [R, ldg]); loss_sum += sum_r (lse_r - logit[r, r + label_offset]) * loss_scale; dscale_sum += sum(G * logits) (divide by
+ * logit_scale for d/d logit_scale).  E % 128 == 0, N % 8 == 0; `workspace` = ocn_fused_logits_ce_workspace_floats(R, N) floats. */
+int64_t ocn_fused_logits_ce_workspace_floats(int R, int N);
+int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
+                        float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
 int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,
                     float bias, float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
                     float* dscale_sum, float* dbias_sum, ocn_stream_t stream);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ocn_l2norm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ocn_l2norm_bwd": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_softmax_ce_rows": [_p, _i, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p],
+    "ocn_fused_logits_ce": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p, _p, _p, _p],
     "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p],
     "ocn_sumsq_accum": [_p, _l, _p, _p],
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
@@ -51,7 +52,8 @@ SIGNATURES = {
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }
-_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_workspace_bytes": ([_i, _i, _i], _l)}
+_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_workspace_bytes": ([_i, _i, _i], _l),
+            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l)}
 
 _lib = None
 _lock = threading.Lock()

@@ -16,7 +16,16 @@ struct GemmNtArgs {
     int first_wave;  // workgroups [0, first_wave) start together (one per CU) and are the ones that get staggered
     int band;    // tile walk order: column bands of `band` n-tiles, row-major inside a band (gemm_nt5.hip)
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
+    // fused logits + cross-entropy epilogues (OCN_EPI_CE_STATS / OCN_EPI_CE_GRAD below; ocn_fused_logits_ce in loss.hip)
+    float* ce_stats;        // STATS: [M][ce_parts][2] per-row (max, sum exp) of each 64-column strip
+    float* ce_label_logit;  // STATS: [M] the logit of the row's label column
+    const float* ce_lse;    // GRAD: [M] log-sum-exp of the whole row
+    float* ce_dscale;       // GRAD: += sum(G * logit)
+    int ce_parts, ce_label_offset;
+    float ce_grad_scale;
 };
+// internal epilogues of the persistent NT kernel (not part of enum ocn_epilogue): the logits tile never leaves the registers
+enum { OCN_EPI_CE_STATS = 5, OCN_EPI_CE_GRAD = 6 };
 
 // chunk swizzle for 128-byte LDS rows: bijection on 3 bits built from row bits 1..3, chosen so that
 // (a) the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots and

@@ -22,6 +22,8 @@
 // ds_write_b64/b128, and stores whole 128-byte rows.
 #include "gemm_args.h"
 
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 namespace {
 
 __device__ long long g_nt5_trace[1024];  // developer timeline (DBG kernels only): 2 workgroups x 8 tiles x 8 stamps
@@ -79,7 +81,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const int gn_w = n0 + wn * 64;
     const int rd_row = lane_o >> 3, rd_chunk = lane_o & 7;
     const unsigned rd_addr = stg + rd_row * 128 + ((rd_chunk ^ rd_row) << 4);  // + it * 1024 for rows it*8 + rd_row
-    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_BIAS_GELU);
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_CE_GRAD);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     // developer knobs 32 / 128: zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued but the
     // bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
@@ -103,6 +105,69 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         for (int hb = 0; hb < 2; ++hb)
             bq[hb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + rd_chunk * 4) * 4, 0, 0));
     }
+    // ---- fused cross-entropy epilogues (ocn_fused_logits_ce): the fp32 logits tile is consumed in the accumulator layout -- a lane
+    // owns ONE row per (ha, s) and 32 of the wave's 64 columns (hb x 16 registers); its other half sits in lane ^ 32.
+    if constexpr (EPI == OCN_EPI_CE_STATS || EPI == OCN_EPI_CE_GRAD) {
+        float ds = 0.f;
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row = m0 + wm * 128 + ha * 64 + s * 32 + lr;
+                const int label = row + a.ce_label_offset;
+                if constexpr (EPI == OCN_EPI_CE_STATS) {
+                    float mx = -INFINITY, lab = 0.f;
+                    bool has = false;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                            const float v = acc[ha][s][hb][r];
+                            if (col < a.N) mx = fmaxf(mx, v);
+                            if (col == label) { lab = v; has = true; }
+                        }
+                    float l = 0.f;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                            if (col < a.N) l += __expf(acc[ha][s][hb][r] - mx);
+                        }
+                    const float mo = __shfl_xor(mx, 32, 64), lo = __shfl_xor(l, 32, 64);
+                    const float m2 = fmaxf(mx, mo);
+                    const float l2 = (mx == -INFINITY ? 0.f : l * __expf(mx - m2)) + (mo == -INFINITY ? 0.f : lo * __expf(mo - m2));
+                    if (row < a.M) {
+                        if (lh == 0) {
+                            float* st = a.ce_stats + ((size_t)row * a.ce_parts + (size_t)(n0 >> 8) * 4 + wn) * 2;
+                            st[0] = m2;
+                            st[1] = l2;
+                        }
+                        if (has) a.ce_label_logit[row] = lab;
+                    }
+                } else {
+                    const float lse = row < a.M ? a.ce_lse[row] : 0.f;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                            const float v = acc[ha][s][hb][r];
+                            const float gv = (__expf(v - lse) - (col == label ? 1.f : 0.f)) * a.ce_grad_scale;
+                            if (row < a.M && col < a.N) ds += gv * v;
+                            acc[ha][s][hb][r] = gv;  // stored as bf16 by the staged path below
+                        }
+                }
+            }
+        if constexpr (EPI == OCN_EPI_CE_STATS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // as below: the next tile's first phases assume every DMA has landed
+            return;
+        } else {
+            ds = wave_sum(ds);
+            if (lane_o == 0) unsafeAtomicAdd(a.ce_dscale, ds);
+        }
+    }
     // Every DMA issued so far must have landed: the first phases of the next tile then need no vmcnt wait and the
     // stores below drain under them.  (hipcc does not know about the asm LDS-DMAs; its own loads / stores below get
     // ordinary counted waits.)
@@ -125,7 +190,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
-                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else v = v + bv[hb][g];
+                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else if (EPI != OCN_EPI_CE_GRAD) v = v + bv[hb][g];
                         if (EPI == OCN_EPI_BIAS_GELU) {
                             f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
                             if (!(a.ablate & 1)) {
@@ -613,6 +678,8 @@ int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
         case OCN_EPI_BIAS_RESID_F32: return launch5<OCN_EPI_BIAS_RESID_F32>(a, st);
         case OCN_EPI_DGELU: return launch5<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch5<OCN_EPI_F32>(a, st);
+        case OCN_EPI_CE_STATS: return launch5<OCN_EPI_CE_STATS>(a, st);
+        case OCN_EPI_CE_GRAD: return launch5<OCN_EPI_CE_GRAD>(a, st);
     }
     return 1;
 }

@@ -1,7 +1,7 @@
 // Row-wise contrastive-loss kernels over materialised fp32 logits (HBM-bound; one workgroup per row).
 // Each produces the loss contribution, the logit gradient G (bf16, the operand of the dI/dT GEMMs) and the
 // logit_scale (/ logit_bias) gradient reductions in one read of the logits + one write of G.
-#include "ocn_common.h"
+#include "gemm_args.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -92,7 +92,68 @@ __global__ __launch_bounds__(256) void siglip_rows_kernel(const float* __restric
     }
 }
 
+// row r: combine the per-strip (max, sum exp) partials of the fused logits pass into lse[r]; loss_sum += (lse - label logit) * loss_scale
+__global__ __launch_bounds__(256) void ce_lse_reduce_kernel(const float* __restrict__ stats, const float* __restrict__ label_logit, float* __restrict__ lse,
+                                                             int R, int parts, float loss_scale, float* __restrict__ loss_sum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float contrib = 0.f;
+    if (row < R) {
+        const float* st = stats + (size_t)row * parts * 2;
+        float m = -INFINITY;
+        for (int p = lane; p < parts; p += 64) m = fmaxf(m, st[2 * p]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int p = lane; p < parts; p += 64) {
+            const float mp = st[2 * p];
+            if (mp != -INFINITY) l += st[2 * p + 1] * __expf(mp - m);
+        }
+        l = wave_sum(l);
+        const float v = m + __logf(l);
+        if (lane == 0) {
+            lse[row] = v;
+            contrib = (v - label_logit[row]) * loss_scale;
+        }
+    }
+    __shared__ float red[4];
+    if (lane == 0) red[wave] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
 }  // namespace
+
+extern "C" int64_t ocn_fused_logits_ce_workspace_floats(int R, int N) { return (int64_t)R * (ocn_cdiv(N, 256) * 4) * 2 + 2 * (int64_t)R; }
+
+// Logits + cross-entropy without the logits: two passes of the persistent NT GEMM over X . Y^T whose epilogues consume the fp32
+// tile in registers -- pass 1 leaves per-row (max, sum exp) partials (one per 64-column strip) and the label logit, a small kernel
+// combines them into the row log-sum-exp and the loss, pass 2 recomputes the tile and writes G = (softmax - onehot) * grad_scale as
+// bf16 plus sum(G * logits).  4 * R * N * E flops instead of 2, and R * N * 2 bytes of HBM writes instead of R * N * (4 + 3 * 4 + 2).
+extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
+                                   float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream) {
+    OCN_CHECK_ARG(X && Y && G && workspace && loss_sum && dscale_sum, "ocn_fused_logits_ce: null operand");
+    OCN_CHECK_ARG(R > 0 && N > 0 && E > 0 && E % 128 == 0 && N % 8 == 0 && ldg % 8 == 0 && ldg >= N && ldx >= E && ldy >= E,
+                  "ocn_fused_logits_ce: unsupported shape R=%d N=%d E=%d (E must be a multiple of 128, N and ldg of 8)", R, N, E);
+    OCN_CHECK_ARG(label_offset >= 0 && label_offset + R <= N, "ocn_fused_logits_ce: labels [%d,%d) outside N=%d", label_offset, label_offset + R, N);
+    OCN_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)G & 15) == 0, "ocn_fused_logits_ce: operands must be 16-byte aligned");
+    GemmNtArgs a;
+    a.A = (const bf16*)X; a.B = (const bf16*)Y; a.out = G; a.bias = nullptr; a.resid = nullptr; a.aux = nullptr;
+    a.lda = ldx; a.ldb = ldy; a.ldc = ldg; a.M = R; a.N = N; a.K = E; a.alpha = 1.0f;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0;
+    const int parts = ocn_cdiv(N, 256) * 4;
+    a.ce_parts = parts; a.ce_label_offset = label_offset; a.ce_grad_scale = grad_scale;
+    a.ce_stats = workspace;
+    a.ce_label_logit = workspace + (size_t)R * parts * 2;
+    float* lse = a.ce_label_logit + R;
+    a.ce_lse = lse; a.ce_dscale = dscale_sum;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ocn_launch_nt5(OCN_EPI_CE_STATS, a, st);
+    if (rc != 0) { if (rc > 0) ocn_set_error("ocn_fused_logits_ce: shape not supported by the persistent GEMM"); return rc > 0 ? OCN_ERR_UNSUPPORTED : rc; }
+    hipLaunchKernelGGL(ce_lse_reduce_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, a.ce_stats, a.ce_label_logit, lse, R, parts, loss_scale, loss_sum);
+    OCN_CHECK_LAUNCH("ocn_fused_logits_ce");
+    rc = ocn_launch_nt5(OCN_EPI_CE_GRAD, a, st);
+    return rc > 0 ? OCN_ERR_UNSUPPORTED : rc;
+}
 
 extern "C" int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset,
                                    float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,

@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import ops
 
 F32, BF16 = torch.float32, torch.bfloat16
+USE_FUSED_CE = True  # tests flip this to compare the fused cross-entropy with the materialised-logits path
 
 
 def _round_up(a, b):
@@ -73,22 +74,36 @@ class _PairTerm:
         self.R, self.N, self.E = X.shape[0], Y.shape[0], X.shape[1]
         self.xs16, self.y16 = _bf16_rows(X, scale), _bf16_rows(Y)
         self.ldg = _round_up(self.N, 64)
-        self.logits = torch.empty(self.R, _round_up(self.N, 4), dtype=F32, device=X.device)[:, :self.N]
+        self.logits = None
+        self._bias = None
         self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
 
     def compute_logits(self, bias=None):
-        """``bias``: None or a 1-element device tensor (SigLIP's logit_bias), broadcast to the epilogue's bias vector"""
-        bvec = None if bias is None else bias.detach().reshape(1).to(F32).expand(self.N).contiguous()
-        ops.gemm_nt(ops.EPI_F32, self.xs16, self.y16, self.logits, bias=bvec)  # bias fused in the epilogue
+        """``bias``: None or a 1-element device tensor (SigLIP's logit_bias), broadcast to the epilogue's bias vector.  The fp32
+        logits are only materialised when a consumer needs them (``siglip``; shapes the fused CE does not take)."""
+        self._bias = bias
         return self
 
+    def _materialise(self):
+        if self.logits is None:
+            self.logits = torch.empty(self.R, _round_up(self.N, 4), dtype=F32, device=self.X.device)[:, :self.N]
+            bvec = None if self._bias is None else self._bias.detach().reshape(1).to(F32).expand(self.N).contiguous()
+            ops.gemm_nt(ops.EPI_F32, self.xs16, self.y16, self.logits, bias=bvec)  # bias fused in the epilogue
+        return self.logits
+
     def softmax_ce(self, label_offset, loss_scale, grad_scale, acc):
-        """rows' CE against arange+offset -> acc[0] += loss, acc[1] += sum(G * logits) (= s * d/dscale); fills G"""
-        ops.softmax_ce_rows(self.logits, self.G, self.N, label_offset, loss_scale, grad_scale, 1.0, acc[0:1], acc[1:2])
+        """rows' CE against arange+offset -> acc[0] += loss, acc[1] += sum(G * logits) (= s * d/dscale); fills G.  Without a bias and
+        on GEMM-sized shapes the logits never exist in memory: two passes of the MFMA GEMM with cross-entropy epilogues
+        (``ocn_fused_logits_ce``: online log-sum-exp, then G) -- at the row-sharded global loss of 8 GPUs ([4096, 32768] per matrix)
+        that is 256 MiB of G written instead of 512 MiB of fp32 logits written and read three times besides."""
+        if self._bias is None and USE_FUSED_CE and ops.fused_logits_ce_supported(self.R, self.N, self.xs16.shape[1]):
+            ops.fused_logits_ce(self.xs16, self.y16, self.G, self.N, label_offset, loss_scale, grad_scale, acc[0:1], acc[1:2])
+            return
+        ops.softmax_ce_rows(self._materialise(), self.G, self.N, label_offset, loss_scale, grad_scale, 1.0, acc[0:1], acc[1:2])
 
     def siglip(self, label_offset, negative_only, loss_scale, grad_scale, acc):
         """acc[0] += loss, acc[1] += sum(G * logits) (bias included: the caller subtracts bias * acc[2]), acc[2] += sum(G)"""
-        ops.siglip_rows(self.logits, self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
+        ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
                         acc[0:1], acc[1:2], acc[2:3])
 
     def dX(self):

@@ -246,6 +246,22 @@ def softmax_ce_rows(logits, G, N, label_offset, loss_scale, grad_scale, inv_logi
               float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _stream())
 
 
+def fused_logits_ce(xs16, y16, G, N, label_offset, loss_scale, grad_scale, loss_sum, dscale_sum):
+    """cross-entropy of the rows of xs16 @ y16[:N]^T against arange + label_offset without materialising the logits
+    (ocn_fused_logits_ce); fills G bf16 [R, ldg], accumulates loss_sum and dscale_sum (= sum(G * logits))"""
+    px, ldx = _chk2d(xs16, BF16, "xs16")
+    py, ldy = _chk2d(y16, BF16, "y16")
+    pg, ldg = _chk2d(G, BF16, "G")
+    R, E = xs16.shape
+    ws = torch.empty(_lib.load().ocn_fused_logits_ce_workspace_floats(R, N), dtype=F32, device=xs16.device)
+    _lib.call("ocn_fused_logits_ce", px, ldx, py, ldy, R, N, E, int(label_offset), float(loss_scale), float(grad_scale), pg, ldg,
+              ws.data_ptr(), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _stream())
+
+
+def fused_logits_ce_supported(R, N, E):
+    return E % 128 == 0 and N % 8 == 0 and R >= 256
+
+
 def siglip_rows(logits, G, N, label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum):
     pl, ld = _chk2d(logits, F32, "logits")
     pg, ldg = _chk2d(G, BF16, "G")

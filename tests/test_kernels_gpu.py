@@ -532,3 +532,61 @@ def test_ops_fail_loudly_on_cpu_tensors(dev):
     with pytest.raises(RuntimeError, match="K=.*multiple of 32"):
         a = torch.zeros(8, 48, dtype=torch.bfloat16, device=dev)
         ops.gemm_nt(ops.EPI_F32, a, a, torch.zeros(8, 8, device=dev))
+
+
+@pytest.mark.parametrize("R,N,E,off", [(4096, 32768, 512, 3 * 4096), (4096, 4096, 512, 0), (300, 1000, 128, 256), (2048, 16384, 768, 2048)])
+def test_fused_logits_cross_entropy(dev, R, N, E, off):
+    """ocn_fused_logits_ce (no materialised logits; the row-sharded global loss of config 3 is [4096 x 32768 x 512]) against fp32
+    torch on the same bf16 operands: loss within 1e-5 relative, G within one bf16 rounding of the fp32 value (+2e-3 of the largest
+    |G| in absolute terms: exp of a recomputed logit), sum(G * logits) within 2e-4 relative."""
+    from open_clip_amd import ops
+    g = torch.Generator(device=dev).manual_seed(R + N)
+    x = torch.nn.functional.normalize(torch.randn(R, E, device=dev, generator=g), dim=-1)
+    y = torch.nn.functional.normalize(torch.randn(N, E, device=dev, generator=g), dim=-1)
+    xs16, y16 = bf(x * 14.2857), bf(y)
+    ldg = (N + 63) // 64 * 64
+    G = torch.zeros(R, ldg, dtype=torch.bfloat16, device=dev)
+    acc = torch.zeros(2, device=dev)
+    ls, gs = 0.5 / R, 0.5 / R
+    assert ops.fused_logits_ce_supported(R, N, E)
+    ops.fused_logits_ce(xs16, y16, G, N, off, ls, gs, acc[0:1], acc[1:2])
+    torch.cuda.synchronize()
+    loss_ref, ds_ref, worst, bad, gmax = 0.0, 0.0, 0.0, 0, 0.0
+    for r0 in range(0, R, 512):
+        sl = slice(r0, min(R, r0 + 512))
+        lg = xs16[sl].float() @ y16.float().t()
+        lab = torch.arange(sl.start, sl.stop, device=dev) + off
+        lse = torch.logsumexp(lg, -1)
+        loss_ref += float(((lse - lg[torch.arange(lg.shape[0]), lab]) * ls).sum())
+        Gref = torch.softmax(lg, -1)
+        Gref[torch.arange(lg.shape[0]), lab] -= 1
+        Gref *= gs
+        ds_ref += float((Gref * lg).sum())
+        got = G[sl, :N].float()
+        gmax = max(gmax, float(Gref.abs().max()))
+        bad += int(((got - Gref).abs() > Gref.abs() * 2.0 ** -7 + 2e-3 * float(Gref.abs().max())).sum())
+        worst = max(worst, rel_l2(got, Gref))
+    _report(f"fused_logits_ce[{R}x{N}x{E}] loss {float(acc[0]):.6f} ref {loss_ref:.6f} dscale {float(acc[1]):.6e} ref {ds_ref:.6e} G rel_l2 {worst:.3e}")
+    assert abs(float(acc[0]) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-6
+    assert abs(float(acc[1]) - ds_ref) <= 2e-4 * abs(ds_ref) + 1e-7
+    assert bad == 0 and worst <= 5e-3
+    assert float(G[:, N:].abs().sum()) == 0.0
+
+
+def test_fused_cross_entropy_gives_the_same_clip_loss_as_the_materialised_path(dev):
+    """NativeClipLoss with and without the fused cross-entropy on the same features (B = 1024, E = 512)"""
+    import open_clip_amd.loss as L
+    g = torch.Generator(device=dev).manual_seed(3)
+    res = []
+    for fused in (True, False):
+        L.USE_FUSED_CE = fused
+        img = torch.nn.functional.normalize(torch.randn(1024, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(1)), dim=-1).requires_grad_(True)
+        txt = torch.nn.functional.normalize(torch.randn(1024, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(2)), dim=-1).requires_grad_(True)
+        s = torch.tensor(14.2857, device=dev, requires_grad=True)
+        loss = L.NativeClipLoss()(img, txt, s)
+        loss.backward()
+        res.append((float(loss.detach()), img.grad.clone(), txt.grad.clone(), float(s.grad)))
+    L.USE_FUSED_CE = True
+    assert abs(res[0][0] - res[1][0]) < 1e-5
+    assert rel_l2(res[0][1], res[1][1]) < 2e-3 and rel_l2(res[0][2], res[1][2]) < 2e-3
+    assert abs(res[0][3] - res[1][3]) <= 1e-3 * abs(res[1][3]) + 1e-8
