@@ -202,11 +202,16 @@ class _BlockFn(torch.autograd.Function):
 
         dy16 = _take_twin(dy)
         dev = x.device
+        # a locked block (lock_image_tower / lock_text_tower with some groups left trainable above it) still has to pass the gradient
+        # down to... nothing that trains: autograd only calls this backward when its INPUT needs a gradient, so the dgrad chain below is
+        # always wanted; the four weight-gradient GEMMs are skipped when none of the block's parameters trains
+        need_w = any(ctx.needs_input_grad[1:13])
         # ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid)))) ----
         df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
         dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev) as side:
-            side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj)
+            if need_w:
+                side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj)
             # dxmid leaves as a (hi, lo) bf16 pair: hi is the operand of the next two GEMMs, hi + lo the residual gradient that the
             # LayerNorm backward below adds in (4 bytes per element instead of fp32 + bf16 twin = 6)
             if _LN_PAIR:
@@ -216,17 +221,21 @@ class _BlockFn(torch.autograd.Function):
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev) as side:
-            side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
+            if need_w:
+                side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
             dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev) as side:
-            side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo)
-            side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv)
+            if need_w:
+                side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo)
+                side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv)
             if _LN_PAIR:
                 dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres_pair=(dxmid16, dxmid_lo), want_f32=True, want_bf16=True)
             else:
                 dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True)
         _publish_twin(dx, dx16)
+        if not need_w:
+            grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None)
 
 
@@ -358,7 +367,7 @@ class Linear(_Params):
     def __init__(self, in_features, out_features):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
-        bound = 1 / math.sqrt(in_features)
+        bound = 1 / math.sqrt(in_features)  # nn.Linear's default (kaiming_uniform_(a=sqrt(5)) == U(+-1/sqrt(in)) for weight and bias)
         self.weight = nn.Parameter(torch.empty(out_features, in_features).uniform_(-bound, bound))
         self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
 
@@ -371,6 +380,7 @@ class Attention(_Params):  # transformer.py:61-155 (fused in_proj, out_proj)
         nn.init.xavier_uniform_(self.in_proj_weight)
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim))
         self.out_proj = Linear(dim, dim)
+        nn.init.zeros_(self.out_proj.bias)  # transformer.py:145-155 (_reset_parameters: "match nn.MultiheadAttention init")
 
 
 class Mlp(_Params):  # transformer.py:295-299 (OrderedDict c_fc / gelu / c_proj)
@@ -421,6 +431,23 @@ class Transformer(nn.Module):  # transformer.py:476-585
         return x
 
 
+def _set_group_requires_grad(members, requires_grad: bool):  # transformer.py:2034-2041
+    for m in members:
+        if isinstance(m, nn.Parameter):
+            m.requires_grad = requires_grad
+        else:
+            for p in m.parameters():
+                p.requires_grad = requires_grad
+
+
+def _lock_layer_groups(groups, unlocked: int = 0):
+    """transformer.py:2044-2053: freeze bottom-up, the top ``unlocked`` groups (projection head first) stay trainable; every group is
+    set explicitly so repeated calls with different counts are idempotent"""
+    n_freeze = len(groups) if not unlocked else len(groups) - unlocked
+    for i, (_, members) in enumerate(groups):
+        _set_group_requires_grad(members, requires_grad=(i >= n_freeze))
+
+
 class _Conv1(_Params):
     def __init__(self, width, patch):
         super().__init__()
@@ -453,7 +480,10 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self._cache = _WeightCache()
         self.image_mean = (0.48145466, 0.4578275, 0.40821073)  # OPENAI_DATASET_MEAN / _STD (constants.py:1-2); used by the
-        self.image_std = (0.26862954, 0.26130258, 0.27577711)  # uint8 input path only (set_model_preprocess_cfg equivalent)
+        self.image_std = (0.26862954, 0.26130258, 0.27577711)  # uint8 input path only
+        # what set_model_preprocess_cfg (model.py:874-878) leaves on the tower: transform.py:18-25 PreprocessCfg as a dict
+        self.preprocess_cfg = {"size": (image_size, image_size), "mode": "RGB", "mean": self.image_mean, "std": self.image_std,
+                               "interpolation": "bicubic", "resize_mode": "shortest", "fill_color": 0}
 
     def set_grad_checkpointing(self, enable=True, impl="inline"):
         self.transformer.set_grad_checkpointing(enable, impl)
@@ -461,10 +491,19 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
     def no_weight_decay(self):  # transformer.py:745-751
         return {"positional_embedding", "class_embedding"}
 
-    def lock(self, unlocked_groups=0, freeze_bn_stats=False):  # transformer.py:753-781 (whole-tower lock only)
-        assert unlocked_groups == 0, "partial unlocking is not supported by the native tower"
-        for p in self.parameters():
-            p.requires_grad = False
+    def layer_groups(self, pooler_in_head: bool = True):
+        """transformer.py:718-743: ordered, complete partition input -> output shared by ``lock`` and layer-wise LR decay:
+        ``embeddings`` (patch conv + class / positional embeddings + ln_pre), ``layer.{i}`` (the last block together with
+        ln_post), ``proj``"""
+        groups = [("embeddings", [self.conv1, self.class_embedding, self.positional_embedding, self.ln_pre])]
+        n = len(self.transformer.resblocks)
+        for i, block in enumerate(self.transformer.resblocks):
+            groups.append((f"layer.{i}", [block] + ([self.ln_post] if i == n - 1 else [])))
+        groups.append(("proj", [self.proj]))
+        return groups
+
+    def lock(self, unlocked_groups=0, freeze_bn_stats=False):  # transformer.py:745-753
+        _lock_layer_groups(self.layer_groups(), unlocked_groups)
 
     def forward(self, image, normalize=False):
         """``image``: float [B,3,H,W] (already normalised, as the reference's transform produces) or uint8 pixels
@@ -490,10 +529,40 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
 class NativeCLIP(nn.Module):
     """Drop-in for ``open_clip.model.CLIP`` (model.py:318-548) on the ViT + causal-text path."""
 
+    # options of the reference's CLIPVisionCfg / CLIPTextCfg / CLIP.__init__ (model.py:27-131, :318-365) that the native path implements,
+    # with the only value it implements for the others (the reference dataclass default): anything else must fail loudly instead of
+    # training a silently different model (e.g. a *-quickgelu config or a SigLIP-style pooling registered through add_model_config)
+    _VISION_KEYS = {"layers", "width", "head_width", "mlp_ratio", "patch_size", "image_size"}
+    _TEXT_KEYS_OK = {"context_length", "vocab_size", "width", "heads", "layers", "mlp_ratio"}
+    _VISION_DEFAULTS = {"ls_init_value": None, "patch_dropout": 0.0, "attentional_pool": False, "pos_embed_type": "learnable", "no_ln_pre": False,
+                        "pool_type": "tok", "final_ln_after_pool": False, "output_tokens": False, "act_kwargs": None, "norm_kwargs": None,
+                        "block_type": None, "qk_norm": False, "scaled_cosine_attn": False, "scale_heads": False, "scale_attn_inner": False,
+                        "scale_attn": False, "scale_fc": False, "timm_model_name": None, "in_chans": 3}
+    _TEXT_DEFAULTS = {"hf_model_name": None, "hf_tokenizer_name": None, "tokenizer_kwargs": None, "tokenizer_mode": None, "ls_init_value": None,
+                      "embed_cls": False, "pad_id": 0, "eos_id": None, "no_causal_mask": False, "final_ln_after_pool": False, "pool_type": "argmax",
+                      "proj_bias": False, "proj_type": "linear", "output_tokens": False, "act_kwargs": None, "norm_kwargs": None, "block_type": None,
+                      "qk_norm": False, "scaled_cosine_attn": False, "scale_heads": False, "scale_attn_inner": False, "scale_attn": False,
+                      "scale_fc": False, "mlp_type": "mlp", "hf_proj_type": None, "hf_pooler_type": None}
+    _MODEL_DEFAULTS = {"quick_gelu": False, "force_quick_gelu": False, "cast_dtype": None, "nonscalar_logit_scale": False, "custom_text": False,
+                       "multimodal_cfg": None}
+
+    @classmethod
+    def _check_cfg(cls, vision_cfg, text_cfg, model_kwargs):
+        for name, cfg, ok, defaults in (("vision_cfg", vision_cfg, cls._VISION_KEYS, cls._VISION_DEFAULTS), ("text_cfg", text_cfg, cls._TEXT_KEYS_OK, cls._TEXT_DEFAULTS),
+                                        ("model", model_kwargs, set(), cls._MODEL_DEFAULTS)):
+            for k, val in cfg.items():
+                if k in ok:
+                    continue
+                if k in defaults and (val == defaults[k] or (val is None and not defaults[k])):
+                    continue
+                raise NotImplementedError(f"NativeCLIP: {name}[{k!r}] = {val!r} is not implemented by the native path "
+                                          f"(supported: {sorted(ok)}; everything else only at the reference default)")
+
     def __init__(self, embed_dim, vision_cfg, text_cfg, init_logit_scale=math.log(1 / 0.07), init_logit_bias=None,
-                 output_dict=False, **_ignored):
+                 output_dict=False, **model_kwargs):
         super().__init__()
         v, t = dict(vision_cfg), dict(text_cfg)
+        self._check_cfg(v, t, model_kwargs)
         self.output_dict = output_dict
         self.embed_dim = embed_dim
         head_width = v.get("head_width", 64)
@@ -517,16 +586,54 @@ class NativeCLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
         self.logit_bias = nn.Parameter(torch.ones([]) * init_logit_bias) if init_logit_bias is not None else None
         self._cache = _WeightCache()
+        self.init_parameters()
+        # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
+        # manual re-initialisation) do not move the counter, so every load_state_dict drops them
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_weight_caches())
+
+    def invalidate_weight_caches(self):
+        """drop the cached bf16 operand copies of the GEMM weights: call after writing to parameters through ``.data`` (anything that
+        does not bump ``Tensor._version``); load_state_dict does it by itself"""
+        self._cache.clear()
+        self.visual._cache.clear()
+
+    def init_parameters(self):
+        """the reference's from-scratch initialisation, drawn from the global RNG (``torch.manual_seed``): text tower
+        transformer.py:1664-1685 (normal inits scaled by width / depth), image tower :641-645, :714 + module defaults
+        (xavier_uniform in_proj, zero attention biases :145-155, nn.Linear defaults for the MLP), logit_scale model.py:326"""
+        tw, tl = self.transformer.width, self.transformer.layers
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        proj_std, attn_std, fc_std = (tw ** -0.5) * ((2 * tl) ** -0.5), tw ** -0.5, (2 * tw) ** -0.5
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=tw ** -0.5)
+
+    def text_layer_groups(self, pooler_in_head: bool = True):
+        """transformer.py:1999-2031 (``_text_layer_groups`` on a CLIP that unpacks the text tower onto itself): ``embeddings``,
+        ``layer.{i}`` (the last block with ln_final), ``proj``"""
+        groups = [("embeddings", [self.token_embedding, self.positional_embedding])]
+        n = len(self.transformer.resblocks)
+        for i, block in enumerate(self.transformer.resblocks):
+            groups.append((f"layer.{i}", [block] + ([self.ln_final] if i == n - 1 else [])))
+        groups.append(("proj", [self.text_projection]))
+        return groups
+
+    def fsdp_shard_modules(self):
+        """base_task.py:234-250: the units FSDP2 shards -- every residual block of both towers (the task's default discovery looks
+        for the reference's block classes, which the native containers are not)"""
+        return [(n, m) for n, m in self.named_modules() if isinstance(m, ResidualAttentionBlock)]
 
     # ---- reference API surface (model.py:369-411) ----
     def lock_image_tower(self, unlocked_groups=0, freeze_bn_stats=False):
         self.visual.lock(unlocked_groups=unlocked_groups, freeze_bn_stats=freeze_bn_stats)
 
     def lock_text_tower(self, unlocked_layers: int = 0, freeze_layer_norm: bool = True, pooler_in_head: bool = True):
-        assert unlocked_layers == 0, "partial unlocking is not supported by the native tower"
-        for n, p in self.named_parameters():
-            if not n.startswith("visual.") and n not in ("logit_scale", "logit_bias"):
-                p.requires_grad = False
+        assert freeze_layer_norm, "Unfreezing LayerNorm is not supported. LayerNorm treated like other weights."  # model.py:373-375
+        _lock_layer_groups(self.text_layer_groups(pooler_in_head), unlocked_layers)
 
     def set_grad_checkpointing(self, enable=True, impl="inline"):
         self.visual.set_grad_checkpointing(enable, impl)
@@ -601,17 +708,26 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     """Counterpart of ``open_clip.factory.create_model`` (factory.py:264-287) for the native path.
     ``pretrained`` may be a local ``.pt`` state-dict path (no hub access); ``precision`` must be an
     amp_bf16-equivalent mode (the kernels implement exactly that policy)."""
-    if precision not in ("amp_bf16", "amp_bfloat16", "bf16", "fp32"):
-        raise ValueError(f"precision {precision!r} not supported by the native path (implements amp_bf16 semantics)")
+    if precision not in ("amp_bf16", "amp_bfloat16"):
+        # the kernels implement exactly one policy: fp32 master weights, bf16 GEMM / attention operands, fp32 accumulation and
+        # statistics (= --precision amp_bf16, precision.py:6-17).  fp32 / pure-bf16 / fp16 callers would silently get other numerics.
+        raise ValueError(f"precision {precision!r} is not supported by the native path: it implements amp_bf16 semantics only")
     cfg = get_model_config(model_name)
+    extra_model_kwargs = {}
     for k, val in model_kwargs.items():
-        cfg[k] = val
+        if k in ("embed_dim", "vision_cfg", "text_cfg"):
+            cfg[k] = val
+        else:
+            extra_model_kwargs[k] = val
+    for k in cfg:
+        if k not in ("embed_dim", "vision_cfg", "text_cfg"):
+            extra_model_kwargs.setdefault(k, cfg[k])
     kw = {}
     if init_logit_scale is not None:
         kw["init_logit_scale"] = init_logit_scale
     if init_logit_bias is not None:
         kw["init_logit_bias"] = init_logit_bias
-    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=bool(output_dict), **kw)
+    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=bool(output_dict), **kw, **extra_model_kwargs)
     if pretrained:
         sd = torch.load(pretrained, map_location="cpu", weights_only=True)
         sd = sd.get("state_dict", sd)

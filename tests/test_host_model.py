@@ -136,3 +136,75 @@ def test_optimizer_state_dict_roundtrip():
     assert opt2.param_groups[0]["lr"] == 1e-3 and opt2.param_groups[1]["weight_decay"] == 0.2
     for p in model.parameters():
         assert opt2.state[p]["step"] == 7 and torch.equal(opt2.state[p]["exp_avg"], torch.full_like(p, 0.5))
+
+
+def test_layer_groups_partial_unlock_and_fsdp_units():
+    """transformer.py:718-753, :1999-2053, base_task.py:234-250 on the native containers: complete ordered partitions, top-down unlock
+    counts (projection head first), idempotent re-locking, one FSDP shard unit per residual block"""
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.model import NativeCLIP
+    cfg = get_model_config("tiny-test")
+    m = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"])
+    vg, tg = m.visual.layer_groups(), m.text_layer_groups()
+    assert [n for n, _ in vg] == ["embeddings", "layer.0", "layer.1", "proj"] and [n for n, _ in tg] == ["embeddings", "layer.0", "layer.1", "proj"]
+
+    def params_of(groups):
+        out = []
+        for _, members in groups:
+            for x in members:
+                out += [x] if isinstance(x, torch.nn.Parameter) else list(x.parameters())
+        return out
+    assert {id(p) for p in params_of(vg)} == {id(p) for p in m.visual.parameters()}
+    text_params = {id(p) for n, p in m.named_parameters() if not n.startswith("visual.") and n not in ("logit_scale", "logit_bias")}
+    assert {id(p) for p in params_of(tg)} == text_params
+    m.lock_image_tower(unlocked_groups=2)  # proj + the last block (with ln_post) stay trainable
+    train = {n for n, p in m.visual.named_parameters() if p.requires_grad}
+    assert "proj" in train and "ln_post.weight" in train and "transformer.resblocks.1.mlp.c_fc.weight" in train
+    assert not any(n.startswith(("conv1", "class_embedding", "positional_embedding", "ln_pre", "transformer.resblocks.0.")) for n in train)
+    m.lock_image_tower(unlocked_groups=0)
+    assert not any(p.requires_grad for p in m.visual.parameters())
+    m.lock_text_tower(unlocked_layers=1)
+    assert m.text_projection.requires_grad and not m.ln_final.weight.requires_grad and not m.token_embedding.weight.requires_grad
+    assert m.logit_scale.requires_grad
+    units = m.fsdp_shard_modules()
+    assert len(units) == 4 and all(n.endswith(("resblocks.0", "resblocks.1")) for n, _ in units)
+    assert m.visual.preprocess_cfg["mean"] == m.visual.image_mean and m.visual.preprocess_cfg["size"] == (64, 64)
+
+
+def test_unsupported_options_fail_loudly_and_init_follows_the_reference_distributions():
+    import math
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.model import NativeCLIP, create_model
+    cfg = get_model_config("tiny-test")
+    with pytest.raises(NotImplementedError, match="quick_gelu"):
+        NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], quick_gelu=True)
+    with pytest.raises(NotImplementedError, match="pool_type"):
+        NativeCLIP(cfg["embed_dim"], dict(cfg["vision_cfg"], pool_type="avg"), cfg["text_cfg"])
+    with pytest.raises(NotImplementedError, match="no_causal_mask"):
+        NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], dict(cfg["text_cfg"], no_causal_mask=True))
+    NativeCLIP(cfg["embed_dim"], dict(cfg["vision_cfg"], pool_type="tok", patch_dropout=0.0), dict(cfg["text_cfg"], pool_type="argmax"), quick_gelu=False)
+    with pytest.raises(ValueError, match="amp_bf16"):
+        create_model("tiny-test", precision="fp32", device="cpu")
+    torch.manual_seed(0)
+    big = get_model_config("ViT-B-32")
+    m = NativeCLIP(big["embed_dim"], big["vision_cfg"], big["text_cfg"])
+    tw, tl = 512, 12
+    blk = m.transformer.resblocks[3]
+    assert abs(float(blk.attn.in_proj_weight.std()) - tw ** -0.5) < 0.03 * tw ** -0.5
+    assert abs(float(blk.mlp.c_fc.weight.std()) - (2 * tw) ** -0.5) < 0.03 * (2 * tw) ** -0.5
+    assert abs(float(blk.attn.out_proj.weight.std()) - tw ** -0.5 * (2 * tl) ** -0.5) < 0.03 * tw ** -0.5
+    assert float(blk.attn.out_proj.bias.abs().max()) == 0.0 and float(blk.attn.in_proj_bias.abs().max()) == 0.0
+    assert abs(float(m.token_embedding.weight.std()) - 0.02) < 1e-3 and abs(float(m.logit_scale) - math.log(1 / 0.07)) < 1e-6
+    vb = m.visual.transformer.resblocks[0]
+    assert float(vb.attn.in_proj_weight.abs().max()) <= math.sqrt(6.0 / (4 * 768)) + 1e-6 and float(vb.attn.out_proj.bias.abs().max()) == 0.0
+
+
+def test_load_state_dict_drops_the_cached_operand_copies():
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.model import NativeCLIP
+    cfg = get_model_config("tiny-test")
+    m = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"])
+    m._cache._d[("x", "n")] = (0, (1,), None)
+    m.visual._cache._d[("y", "n")] = (0, (1,), None)
+    m.load_state_dict(m.state_dict())
+    assert not m._cache._d and not m.visual._cache._d

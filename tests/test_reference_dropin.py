@@ -83,3 +83,28 @@ def test_reference_train_one_epoch_drives_the_native_task():
 
     with pytest.raises(RuntimeError, match="no CPU path"):
         train_one_epoch(TrainState(task=task, optimizer=opt), {"train": Data()}, args)
+
+
+def test_layer_groups_and_partial_locks_match_the_reference():
+    """``visual.layer_groups()`` / the text groups name the same partitions as the reference's (transformer.py:718-743, :1999-2031) and
+    ``lock_image_tower(unlocked_groups=k)`` / ``lock_text_tower(unlocked_layers=k)`` freeze exactly the same parameters"""
+    open_clip, ref, native = _pair()
+    from open_clip.transformer import _text_layer_groups
+
+    def names_by_group(model, groups, prefix=""):
+        ids = {id(p): n for n, p in model.named_parameters()}
+        out = []
+        for gname, members in groups:
+            ps = []
+            for m in members:
+                ps += [m] if isinstance(m, torch.nn.Parameter) else list(m.parameters())
+            out.append((gname, sorted(ids[id(p)] for p in ps)))
+        return out
+    assert names_by_group(native, native.visual.layer_groups()) == names_by_group(ref, ref.visual.layer_groups())
+    assert names_by_group(native, native.text_layer_groups()) == names_by_group(ref, _text_layer_groups(ref))
+    for k in (0, 1, 3, 14):
+        ref.lock_image_tower(unlocked_groups=k)
+        native.lock_image_tower(unlocked_groups=k)
+        ref.lock_text_tower(unlocked_layers=k)
+        native.lock_text_tower(unlocked_layers=k)
+        assert {n for n, p in ref.named_parameters() if p.requires_grad} == {n for n, p in native.named_parameters() if p.requires_grad}, k
