@@ -11,7 +11,9 @@
  *   - plain pointers + sizes; the caller owns all memory (device pointers unless stated otherwise);
  *     the library never allocates.
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (async).
- *   - re-entrant, no global device state (the backward pass runs on the autograd thread).
+ *   - re-entrant, no global device state (the backward pass runs on the autograd thread).  The only process-global state in the
+ *     library are the developer knobs of include/openclip_hip_debug.h (kernel selection / ablation switches for experiments:
+ *     never needed, never touched by the product path, defaults = the shipped behaviour).
  *   - return 0 on success, negative ocn_status on error; ocn_last_error() holds the message
  *     (thread-local).  Python wrappers turn that into RuntimeError, like the reference's asserts.
  *   - "bf16" buffers are raw 16-bit bfloat16; residual stream, statistics, losses and weight
@@ -64,26 +66,6 @@ int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW,
 int64_t ocn_gemm_tn_workspace_bytes(int M, int N, int K);
 int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
                          float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream);
-
-/* tuning hook (process-global; tools/gemm_bench.py and the tests use it to cover every kernel):
- *   bits 0..3  NT kernel: 0 auto, 1 128x128 two-stage, 2 256x256 two-stage, 3 256x128 two-stage, 4 256x256 4-stage ring
- *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
- *   bits 8..   developer knobs of the persistent NT kernel: (v >> 8) & 1 skip GELU arithmetic (results wrong), & 2 / & 8 flip the
- *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 64 timeline
- *              build; (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off) */
-int ocn_set_gemm_variant(int nt_variant);
-/* developer knobs (process-global; experiments and A/B measurements of tools/sweep.py, never needed by a user):
- *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)
- *   key 2  attention backward: 3 = the 168-VGPR build (3 waves per SIMD)      key 4  wgrad GEMM: 1 = skip the atomic epilogue
- *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
- *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
- *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
- *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
- *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step) */
-int ocn_set_tuning(int key, int value);
-/* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
- * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */
-int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_stream_t stream);
 
 /* ---- casts -------------------------------------------------------------------------------------
  * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */

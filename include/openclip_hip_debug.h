@@ -1,0 +1,42 @@
+/*
+ * openclip_hip_debug.h -- DEVELOPER entry points of libopenclip_hip.so: kernel-selection and ablation knobs used by the experiment
+ * tools (tools/gemm_bench.py, tools/sweep.py, tools/occupancy_hazard_probe.py, tools/gemm_trace.py) and by tests that force a
+ * fallback kernel.  NOT part of the drop-in boundary (include/openclip_hip.h): the knobs are process-global, several of them
+ * deliberately produce WRONG results (they skip arithmetic or memory traffic to time what is left), and nothing in open_clip_amd/
+ * calls them.  Defaults (all zero) are the shipped behaviour.
+ */
+#ifndef OPENCLIP_HIP_DEBUG_H
+#define OPENCLIP_HIP_DEBUG_H
+#include "openclip_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel choice of ocn_gemm_nt / ocn_gemm_tn_accum (process-global):
+ *   bits 0..3  NT kernel: 0 auto, 1 128x128 two-stage, 2 256x256 two-stage, 3 256x128 two-stage, 4 256x256 4-stage ring
+ *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
+ *   bits 8..   developer knobs of the persistent NT kernel: (v >> 8) & 1 skip GELU arithmetic (results wrong), & 2 / & 8 flip the
+ *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 64 timeline
+ *              build; (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off) */
+int ocn_set_gemm_variant(int nt_variant);
+/* developer knobs (process-global; experiments and A/B measurements of tools/sweep.py, never needed by a user):
+ *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)
+ *   key 2  attention backward: 3 = the 168-VGPR build (3 waves per SIMD)      key 4  wgrad GEMM: 1 = skip the atomic epilogue
+ *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
+ *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
+ *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
+ *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
+ *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step) */
+int ocn_set_tuning(int key, int value);
+/* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
+ * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */
+int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_stream_t stream);
+
+/* per-tile timeline of the persistent NT kernel's developer build (knob bit 64): copies 1024 int64 stamps to host_out */
+int ocn_debug_nt5_trace(long long* host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

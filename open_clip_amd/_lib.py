@@ -18,9 +18,6 @@ SIGNATURES = {
     "ocn_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p],
     "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
     "ocn_gemm_tn_accum_ws": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p, _l, _p],
-    "ocn_set_gemm_variant": [_i],
-    "ocn_set_tuning": [_i, _i],
-    "ocn_debug_occupy": [_i, _i, _p, _p],
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
@@ -52,6 +49,14 @@ SIGNATURES = {
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }
+# developer entry points (include/openclip_hip_debug.h): kernel selection / ablation knobs for tools/ and a few tests; never called by
+# the product modules
+DEBUG_SIGNATURES = {
+    "ocn_set_gemm_variant": [_i],
+    "ocn_set_tuning": [_i, _i],
+    "ocn_debug_occupy": [_i, _i, _p, _p],
+    "ocn_debug_nt5_trace": [_p],
+}
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_workspace_bytes": ([_i, _i, _i], _l),
             "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l)}
 
@@ -75,7 +80,7 @@ def load():
         import torch  # noqa: F401  -- BEFORE the CDLL: the library must bind to the HIP runtime torch has loaded (its bundled
         #                 libamdhip64), not pull a second copy from /opt/rocm that knows no device ("no ROCm-capable device")
         lib = ctypes.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
+        for name, argtypes in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = _i

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/openclip_hip.h"
+#include "../../include/openclip_hip_debug.h"
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

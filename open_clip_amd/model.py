@@ -66,27 +66,24 @@ class _WeightCache:
 # ------------------------------------------------------------------------------------------------------
 # bf16 twins of residual-stream gradients: the kernel that produces a block's input gradient (LayerNorm backward)
 # also emits it in bf16, and the previous block's backward uses that as its GEMM operand instead of running a cast
-# kernel over the fp32 gradient (saves one 4-byte read per element per block).  Keyed by storage pointer and checked
-# against shape / version; a miss simply falls back to the cast.
+# kernel over the fp32 gradient (saves one 4-byte read per element per block).  The twin TRAVELS WITH THE GRADIENT TENSOR
+# (an attribute on the tensor object autograd hands from one Function's backward to the next, stamped with the tensor's
+# version counter): nothing is keyed by address, nothing outlives the tensor, and a consumer that receives any other
+# tensor (autograd summed two branches, a hook replaced the gradient, ...) finds no attribute and casts.
 # ------------------------------------------------------------------------------------------------------
-_GRAD_TWINS = {}
+TWIN_STATS = {"hit": 0, "miss": 0}  # how often the hand-off was taken (tests assert it is; a miss costs one cast kernel, never correctness)
 
 
 def _publish_twin(g32, g16):
-    _GRAD_TWINS.clear()  # at most one live hand-off per tower chain at a time
-    _GRAD_TWINS[g32.data_ptr()] = (g32.shape, g32._version, g16)
-
-
-def _drop_twins():
-    """called where a tower's backward chain starts (head) and ends (embedding): a hand-off that nobody took must not
-    outlive its chain -- the registry is keyed by address, and the allocator re-uses addresses from step to step"""
-    _GRAD_TWINS.clear()
+    g32._ocn_bf16_twin = (g16, g32._version)
 
 
 def _take_twin(g32):
-    hit = _GRAD_TWINS.pop(g32.data_ptr(), None)
-    if hit is not None and hit[0] == g32.shape and hit[1] == g32._version:
-        return hit[2]
+    tw = getattr(g32, "_ocn_bf16_twin", None)
+    if tw is not None and tw[1] == g32._version and tw[0].shape == g32.shape and tw[0].device == g32.device:
+        TWIN_STATS["hit"] += 1
+        return tw[0]
+    TWIN_STATS["miss"] += 1
     return ops.cast_bf16(g32)
 
 
@@ -271,7 +268,6 @@ class _VisionEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx0):
-        _drop_twins()
         patches, emb, mean, rstd, lnw, conv_w, cls, pos = ctx.saved_tensors
         B, G, width, KP, Kpad = ctx.meta
         dev = emb.device
@@ -297,7 +293,6 @@ class _TextEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx):
-        _drop_twins()
         text, table, pos = ctx.saved_tensors
         dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
         ops.token_embed_bwd(text.contiguous(), dx.contiguous(), dtable, dpos)
@@ -339,7 +334,6 @@ class _HeadFn(torch.autograd.Function):
         dx = torch.zeros(xshape, dtype=F32, device=dy.device)
         dx16 = torch.zeros(xshape, dtype=BF16, device=dy.device)  # bf16 twin for the last block's dgrad / wgrad GEMMs
         ops.scatter_rows(dpooled, idx, dx, B, L, dx16)
-        _drop_twins()
         _publish_twin(dx, dx16)
         return dx, dlnw, dlnb, dproj, None, None, None, None, None
 

@@ -9,8 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "openclip_hip.h")
 
 
-def _declared():
-    src = open(HEADER).read()
+DEBUG_HEADER = os.path.join(ROOT, "include", "openclip_hip_debug.h")
+
+
+def _declared(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ocn_[a-z0-9_]+)\s*\(", src)))
 
@@ -26,12 +29,15 @@ def test_header_declares_the_python_table(lib_path):
     declared = _declared()
     table = sorted(list(_lib.SIGNATURES) + list(_lib._SPECIAL))
     assert declared == table, (set(declared) ^ set(table))
+    # the developer knobs live in their own header and table: none of them is part of the boundary
+    assert _declared(DEBUG_HEADER) == sorted(_lib.DEBUG_SIGNATURES), set(_declared(DEBUG_HEADER)) ^ set(_lib.DEBUG_SIGNATURES)
+    assert not set(declared) & set(_lib.DEBUG_SIGNATURES)
 
 
 def test_library_exports_every_declared_symbol(lib_path):
     out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (ocn_[a-z0-9_]+)", out))
-    missing = set(_declared()) - exported
+    missing = (set(_declared()) | set(_declared(DEBUG_HEADER))) - exported
     assert not missing, missing
 
 
