@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--h2d", action="store_true", help="feed every step from pinned HOST memory: uint8 [B,H,W,3] pixels + tokens, double-buffered "
                     "async copies on a copy stream, normalisation inside the patch kernel (open_clip_amd/input_pipeline.py); the copies are "
                     "inside the timed region")
+    ap.add_argument("--force-ddp", action="store_true", help="developer: with one process, still wrap the model in DistributedDataParallel over a "
+                    "one-rank RCCL group (what the gradient buckets, their copies and the reducer hooks cost without any communication)")
+    ap.add_argument("--bucket-cap-mb", type=int, default=128)
     ap.add_argument("--data-ranks", type=int, default=1, help="developer: with one process, use the concatenation of the batches R ranks would "
                     "get (what a world_size-R run sees as its global batch; tests/test_bench_gpu.py)")
     ap.add_argument("--lr", type=float, default=5e-4)
@@ -184,6 +187,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1 and args.force_ddp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29777")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -241,8 +249,8 @@ def main():
                                  row_sharded=(world > 1 and not args.naive_global_loss))
     opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=args.lr, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=128, gradient_as_bucket_view=True)
+    if world > 1 or args.force_ddp:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_cap_mb, gradient_as_bucket_view=True)
 
     timer = GemmTimer()
     if not args.no_roofline:
@@ -337,6 +345,7 @@ def main():
                                    + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
                                       if world > 1 else "world_size 1 (no all-gather)"),
                        "model": args.model, "global_batch": B * F_ACC * world, "local_batch": B, "accum_freq": F_ACC, "parallelism": f"dp{world}",
+                       "ddp": bool(world > 1 or args.force_ddp), "bucket_cap_mb": args.bucket_cap_mb,
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             "step_model_tflops_per_gpu": round(value / world * flops_pair / 1e3, 1),
@@ -372,7 +381,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         torch.distributed.destroy_process_group()
 
 

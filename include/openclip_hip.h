@@ -137,6 +137,12 @@ int ocn_token_embed_fwd(const int64_t* text, const float* table, const float* po
 int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* dtable, float* dpos, int B, int L, int C, int vocab,
                         ocn_stream_t stream);
 
+/* The same backward from SORTED ids (no per-occurrence atomics): sorted_tokens = the B*L token ids in ascending order, order[i] = the flat
+ * row (b*L + l) of dx that sorted_tokens[i] came from (any stable or unstable sort; torch.sort on the device).  dtable must arrive ZEROED
+ * (complete runs are stored, not added); dpos is accumulated into. */
+int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const float* dx, float* dtable, float* dpos, int B, int L,
+                               int C, int vocab, ocn_stream_t stream);
+
 /* ---- pooling (transformer.py:786-787 'tok'; :941-944 'argmax') ---------------------------------
  * argmax_rows: idx[b] = first index of max(text[b,:]) (torch.argmax semantics)
  * gather_rows: out[b,:] = x[(b*L + idx[b]),:] (idx NULL -> token 0);  scatter_rows: dx (pre-zeroed)[b*L+idx[b],:] = d[b,:] */

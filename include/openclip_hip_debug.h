@@ -33,6 +33,8 @@ int ocn_set_tuning(int key, int value);
  * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */
 int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_stream_t stream);
 
+/* developer probe: creates a HIP stream restricted to the compute units whose bits are set in mask[0..nwords) (hipExtStreamCreateWithCUMask) */
+int ocn_debug_stream_with_cu_mask(const uint32_t* mask, int nwords, void** stream_out);
 /* per-tile timeline of the persistent NT kernel's developer build (knob bit 64): copies 1024 int64 stamps to host_out */
 int ocn_debug_nt5_trace(long long* host_out);
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ocn_embed_assemble_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_token_embed_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ocn_token_embed_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ocn_token_embed_bwd_sorted": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],
     "ocn_gather_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ocn_scatter_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -56,6 +57,7 @@ DEBUG_SIGNATURES = {
     "ocn_set_tuning": [_i, _i],
     "ocn_debug_occupy": [_i, _i, _p, _p],
     "ocn_debug_nt5_trace": [_p],
+    "ocn_debug_stream_with_cu_mask": [_p, _i, _p],
 }
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_workspace_bytes": ([_i, _i, _i], _l),
             "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l)}

@@ -79,6 +79,19 @@ extern "C" int ocn_debug_occupy(int n_workgroups, int micros, int* sink, ocn_str
     return OCN_OK;
 }
 
+// developer probe: a HIP stream whose kernels may only run on the CUs named in `mask` (bit i of word i/32 = CU i); tools/cu_mask_probe.py
+extern "C" int ocn_debug_stream_with_cu_mask(const uint32_t* mask, int nwords, void** stream_out) {
+    OCN_CHECK_ARG(mask && nwords > 0 && stream_out, "ocn_debug_stream_with_cu_mask: bad arguments");
+    hipStream_t st = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask);
+    if (e != hipSuccess) {
+        ocn_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+        return OCN_ERR_LAUNCH;
+    }
+    *stream_out = (void*)st;
+    return OCN_OK;
+}
+
 extern "C" int ocn_probe_mfma32(const void* a, const void* b, float* c, ocn_stream_t stream) {
     hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, c);
     OCN_CHECK_LAUNCH("ocn_probe_mfma32");

@@ -184,6 +184,57 @@ __global__ void token_embed_bwd_kernel(const int64_t* __restrict__ text, const f
     unsafeAtomicAdd(dpos + (size_t)l * C + c, acc);
 }
 
+// The same gradient from SORTED token ids (segment reduce instead of one fp32 atomic per (token, column)): `keys` = the flat token ids
+// in ascending order, `order[i]` = the flat (b*L + l) row of dx that keys[i] came from.  A workgroup walks CH consecutive entries with
+// one float4 of columns per thread; a run of equal ids that starts and ends inside the chunk (and is bounded by different ids on both
+// sides) is complete and is STORED (dtable arrives zeroed), only runs that cross a chunk boundary -- the zero padding, SOT / EOT --
+// are added atomically, once per chunk instead of once per occurrence.  0.29 ms instead of 1.43 ms at B = 4096 (+ the sort).
+__global__ __launch_bounds__(128) void token_embed_bwd_sorted_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__ order,
+                                                                     const float* __restrict__ dx, float* __restrict__ dtable, long n, int C,
+                                                                     int vocab, int CH) {
+    const long i0 = (long)blockIdx.x * CH, i1 = min(n, i0 + CH);
+    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        long cur = -1, seg_start = i0;
+        for (long i = i0; i <= i1; ++i) {
+            long tok = -2;
+            if (i < i1) {
+                tok = keys[i];
+                tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+            }
+            if (tok != cur) {
+                if (cur >= 0) {
+                    const bool closed_l = seg_start > i0 || i0 == 0 || keys[i0 - 1] != keys[i0];
+                    const bool closed_r = i < i1 || i1 == n || keys[i1] != keys[i1 - 1];
+                    float* d = dtable + (size_t)cur * C + c;
+                    if (closed_l && closed_r) {
+                        *(f32x4*)d = acc;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d + e, acc[e]);
+                    }
+                }
+                cur = tok;
+                seg_start = i;
+                acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (i < i1) acc += *(const f32x4*)(dx + (size_t)order[i] * C + c);
+        }
+    }
+}
+
+// dpos[l, :] += sum_b dx[b, l, :]   (one float4 of columns per thread, a chunk of the batch per workgroup row)
+__global__ void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int B, int L, int C, int bchunk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, c4n = C / 4;
+    if (idx >= L * c4n) return;
+    const int l = idx / c4n, c = (idx % c4n) * 4;
+    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0; b < b1; ++b) acc += *(const f32x4*)(dx + ((size_t)b * L + l) * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dpos + (size_t)l * C + c + e, acc[e]);
+}
+
 // ---- pooling ---------------------------------------------------------------------------------------
 __global__ void argmax_rows_kernel(const int64_t* __restrict__ text, int32_t* __restrict__ idx, int B, int L) {
     const int lane = threadIdx.x & 63;
@@ -364,6 +415,21 @@ extern "C" int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* 
     dim3 grid(ocn_cdiv((long)L * C, 256), ocn_cdiv(B, bchunk));
     hipLaunchKernelGGL(token_embed_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, text, dx, dtable, dpos, B, L, C, vocab, bchunk);
     OCN_CHECK_LAUNCH("ocn_token_embed_bwd");
+    return OCN_OK;
+}
+
+extern "C" int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const float* dx, float* dtable, float* dpos, int B, int L,
+                                          int C, int vocab, ocn_stream_t stream) {
+    OCN_CHECK_ARG(sorted_tokens && order && dx && dtable && dpos, "ocn_token_embed_bwd_sorted: null operand");
+    OCN_CHECK_ARG(B > 0 && L > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_bwd_sorted: bad shape");
+    OCN_CHECK_ARG(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dtable & 15) == 0, "ocn_token_embed_bwd_sorted: operands must be 16-byte aligned");
+    const long n = (long)B * L;
+    const int CH = 64;
+    hipLaunchKernelGGL(token_embed_bwd_sorted_kernel, dim3((unsigned)ocn_cdiv(n, CH)), dim3(128), 0, (hipStream_t)stream, sorted_tokens, order, dx, dtable,
+                       n, C, vocab, CH);
+    const int bchunk = 128;
+    hipLaunchKernelGGL(pos_grad_kernel, dim3(ocn_cdiv((long)L * (C / 4), 256), ocn_cdiv(B, bchunk)), dim3(256), 0, (hipStream_t)stream, dx, dpos, B, L, C, bchunk);
+    OCN_CHECK_LAUNCH("ocn_token_embed_bwd_sorted");
     return OCN_OK;
 }
 

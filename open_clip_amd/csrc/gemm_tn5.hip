@@ -341,7 +341,9 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     a.tiles_k = ocn_cdiv(a.K, 256);
     const int ntile = a.tiles_n * a.tiles_k;
     const int msteps = ocn_cdiv(a.M, 32);
-    int splits = g_tn5_num_cu / ntile;  // one workgroup per CU ...
+    // developer knob 15 = n: size the grid for n CUs (a stream restricted to a CU subset, tools/cu_mask_probe.py)
+    const int cus = (g_ocn_tuning[15] > 0 && g_ocn_tuning[15] < g_tn5_num_cu) ? g_ocn_tuning[15] : g_tn5_num_cu;
+    int splits = cus / ntile;  // one workgroup per CU ...
     // ... developer knob 11 = k: k per CU when the M-chunks stay long (<= 10 splits).  A workgroup that starts late because its CU
     // is held by another stream's kernel then costs 1/k as much (one CU held: +43 % at k = 1, +7 % at k = 2;
     // profiles/r01_persistent_gemm_occupancy_hazard.txt), but the finer split costs 4-8 % in steady state on exactly those big

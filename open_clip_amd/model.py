@@ -107,6 +107,9 @@ _SIDE = {}
 # bf16 twin (4 instead of 6 bytes written per element).  Measured 0.6 % SLOWER on the step (two 8-byte accesses per lane instead of
 # one 16-byte one, and the pair cannot use the non-temporal policy of the fp32 copy), so it is off.
 _LN_PAIR = _os.environ.get("OCN_LN_PAIR", "0") == "1"
+# OCN_WGRAD_PAIR (experiment): which HBM-bound kernels get a wgrad GEMM beside them -- "all" (default), "attn" (only the attention
+# backward; the two LayerNorm backwards run alone and their wgrads follow on the main stream), "ln" (only the LayerNorm backwards)
+_PAIR_MODE = _os.environ.get("OCN_WGRAD_PAIR", "all")
 
 
 def _side_stream(dev):
@@ -122,8 +125,8 @@ class _Paired:
     """``with _Paired(dev) as side: side(fn, ...)`` enqueues fn on the side stream after everything already on the main
     stream; leaving the block joins the side stream back into the main stream."""
 
-    def __init__(self, dev):
-        self.side = _side_stream(dev)
+    def __init__(self, dev, enabled=True):
+        self.side = _side_stream(dev) if enabled else None
         self.main = torch.cuda.current_stream(dev) if self.side is not None else None
 
     def __enter__(self):
@@ -206,7 +209,7 @@ class _BlockFn(torch.autograd.Function):
         # ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid)))) ----
         df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
         dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev) as side:
+        with _Paired(dev, _PAIR_MODE in ("all", "ln")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj)
             # dxmid leaves as a (hi, lo) bf16 pair: hi is the operand of the next two GEMMs, hi + lo the residual gradient that the
@@ -217,12 +220,12 @@ class _BlockFn(torch.autograd.Function):
                 dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev) as side:
+        with _Paired(dev, _PAIR_MODE in ("all", "attn")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
             dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev) as side:
+        with _Paired(dev, _PAIR_MODE in ("all", "ln")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo)
                 side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv)
@@ -295,7 +298,7 @@ class _TextEmbedFn(torch.autograd.Function):
     def backward(ctx, dx):
         text, table, pos = ctx.saved_tensors
         dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
-        ops.token_embed_bwd(text.contiguous(), dx.contiguous(), dtable, dpos)
+        ops.token_embed_bwd_sorted(text.contiguous(), dx.contiguous(), dtable, dpos)
         return None, dtable, dpos
 
 

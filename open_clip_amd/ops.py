@@ -204,6 +204,16 @@ def token_embed_bwd(text, dx, dtable, dpos):
               _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
 
 
+def token_embed_bwd_sorted(text, dx, dtable, dpos):
+    """segment-reduce form of token_embed_bwd: ``dtable`` must be zero on entry.  The device sort of the B*L ids is index plumbing
+    (torch.sort); all arithmetic is in ocn_token_embed_bwd_sorted."""
+    B, L = text.shape
+    vocab, C = dtable.shape
+    keys, order = torch.sort(text.reshape(-1))
+    _lib.call("ocn_token_embed_bwd_sorted", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"), _chk(dx, F32, "dx"),
+              _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
+
+
 def argmax_rows(text):
     B, L = text.shape
     idx = empty((B,), torch.int32, text)

@@ -400,6 +400,10 @@ def test_text_embed_and_pool_kernels(dev):
     ref = torch.zeros_like(table).index_add_(0, text.reshape(-1), dx)
     check("token_embed_bwd dtable", dtable, ref, rel=1e-5)
     check("token_embed_bwd dpos", dpos, dx.reshape(B, L, C).sum(0), rel=1e-5)
+    dtable2, dpos2 = torch.zeros_like(table), torch.zeros_like(pos)
+    ops.token_embed_bwd_sorted(text, dx, dtable2, dpos2)
+    check("token_embed_bwd_sorted dtable", dtable2, ref, rel=1e-5)
+    check("token_embed_bwd_sorted dpos", dpos2, dx.reshape(B, L, C).sum(0), rel=1e-5)
     pooled = ops.gather_rows(x, idx, B, L)
     assert torch.equal(pooled, x.reshape(B, L, C)[torch.arange(B), idx.long()])
     assert torch.equal(ops.gather_rows(x, None, B, L), x.reshape(B, L, C)[:, 0])
@@ -590,3 +594,20 @@ def test_fused_cross_entropy_gives_the_same_clip_loss_as_the_materialised_path(d
     assert abs(res[0][0] - res[1][0]) < 1e-5
     assert rel_l2(res[0][1], res[1][1]) < 2e-3 and rel_l2(res[0][2], res[1][2]) < 2e-3
     assert abs(res[0][3] - res[1][3]) <= 1e-3 * abs(res[1][3]) + 1e-8
+
+
+def test_token_embed_backward_sorted_at_bench_size(dev):
+    """the segment-reduce embedding backward at the bench's size and token statistics (B 4096 x 77 tokens of a 49408-entry table: SOT
+    at position 0, one EOT, zero padding behind it -- runs of thousands of equal ids that cross many chunks) against index_add_"""
+    from open_clip_amd import ops
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.synth import synthetic_batch
+    cfg = get_model_config("ViT-B-32")
+    text = synthetic_batch(cfg, 4096, seed=7)["text"].to(dev)
+    B, L, C, V = 4096, 77, 512, 49408
+    dx = torch.randn(B * L, C, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    dtable, dpos = torch.zeros(V, C, device=dev), torch.zeros(L, C, device=dev)
+    ops.token_embed_bwd_sorted(text, dx, dtable, dpos)
+    ref = torch.zeros(V, C, device=dev, dtype=torch.float64).index_add_(0, text.reshape(-1), dx.double())
+    check("token_embed_bwd_sorted[4096x77x512] dtable", dtable, ref, rel=2e-6)
+    check("token_embed_bwd_sorted[4096x77x512] dpos", dpos, dx.reshape(B, L, C).double().sum(0), rel=2e-6)
