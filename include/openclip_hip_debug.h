@@ -14,8 +14,8 @@ extern "C" {
 #endif
 
 /* kernel choice of ocn_gemm_nt / ocn_gemm_tn_accum (process-global):
- *   bits 0..3  NT kernel: 0 auto, 1 128x128 two-stage, 2 256x256 two-stage, 3 256x128 two-stage, 4 256x256 4-stage ring
- *   bits 4..7  TN kernel: 0 auto, 1 128x128 two-stage, 2 256x256 4-stage ring
+ *   bits 0..3  NT kernel: 0 auto, 4 the general 256x256 ring kernel, 5 the persistent 256x256 kernel (falls back to 4)
+ *   bits 4..7  TN kernel: 0 auto, 1 the general 128x128 kernel, 3 the hand-scheduled 256x256 kernel (falls back to 1)
  *   bits 8..   developer knobs of the persistent NT kernel: (v >> 8) & 1 skip GELU arithmetic (results wrong), & 2 / & 8 flip the
  *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 64 timeline
  *              build; (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off) */

@@ -3,14 +3,13 @@
 //   ocn_gemm_nt        C[M,N]  = A[M,K] . B[N,K]^T  (+ fused epilogue)      forward linears, dgrads, logits
 //   ocn_gemm_tn_accum  dW[N,K] += A[M,N]^T . B[M,K] (+ dbias = colsum(A))   wgrads, loss G^T products
 //
-// Both: 128x128 workgroup tile, 4 waves (2x2), each wave a 64x64 sub-tile as 2x2 v_mfma_f32_32x32x16_bf16
-// accumulators; operands reach LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a
-// double-buffered 2 x 32 KiB ring, one barrier per K-step; two workgroups per CU so one workgroup's
-// epilogue overlaps the other's main loop.  LDS images are XOR-swizzled on the *source* address (the DMA
-// destination is lane-linear) so that fragment reads are bank-conflict free:
-//   NT  : rows of 64 bf16 (128 B), ds_read_b128 fragments, chunk ^= f(row)          (f: see swz_nt)
-//   TN  : rows of 128 bf16 (256 B), ds_read_b64_tr_b16 transposing reads, chunk ^= (row&3)<<2
-// Tiles are walked in an XCD-aware order (ocn_common.h xcd_remap).
+// The tower-sized launches go to the hand-scheduled persistent kernels (gemm_nt5.hip, gemm_tn5.hip).  This file holds the C entry
+// points, the dispatch and ONE general kernel per operation for everything those do not take (small or ragged shapes: pooled
+// heads at tiny batch, K % 128 != 0, N % 8 != 0, test configurations):
+//   NT  : 256x256 tile, 8 waves, K in steps of 32 through a 4-stage LDS ring (LDS-DMA, counted vmcnt), scalar epilogue for N % 4
+//   TN  : 128x128 tile of dW, 4 waves, rows of 128 bf16 (256 B), ds_read_b64_tr_b16 transposing reads, fp32 atomics
+// LDS images are XOR-swizzled on the *source* address (the DMA destination is lane-linear).  Tiles are walked in an XCD-aware
+// order (ocn_common.h xcd_remap).
 #include "gemm_args.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
@@ -23,57 +22,6 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
 constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // double buffered: 64 KiB -> 2 workgroups / CU
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];  // zero source for out-of-range DMA lanes
-
-// rows [row0, row0+ROWS) x k [k0, k0+64) of a row-major bf16 matrix -> LDS tile (rows clamped), NW waves
-template <int ROWS, int NW>
-OCN_DEV void stage_nt(const bf16* __restrict__ G, int ld, int row0, int nrows, int k0, char* sT, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < ROWS / 8 / NW; ++j) {
-        const int seg = wave + j * NW;  // 8 rows per wave-instruction
-        const int r = seg * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ swz_nt(r);
-        int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1;
-        glds16(G + (size_t)gr * ld + k0 + c * 8, (OCN_LDS void*)(sT + seg * 1024));
-    }
-}
-
-template <int EPI>
-OCN_DEV void epilogue_store4(const GemmNtArgs& a, int gm, int gn, f32x4 v) {
-    const size_t o = (size_t)gm * a.ldc + gn;
-    if (a.bias) {
-        const f32x4 b = *(const f32x4*)(a.bias + gn);
-        if (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_F32) v = v * a.alpha + b; else v = v + b;
-    } else if (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_F32) {
-        v = v * a.alpha;
-    }
-    if (EPI == OCN_EPI_BF16) {
-        bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *(bf16x4*)((bf16*)a.out + o) = o4;
-    } else if (EPI == OCN_EPI_BIAS_GELU) {
-        f32x4 gv, dv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float g1, d1;
-            gelu_both(v[e], g1, d1);
-            gv[e] = g1;
-            dv[e] = d1;
-        }
-        bf16x4 p4 = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])};  // aux = gelu'(pre-activation)
-        *(bf16x4*)(a.aux + o) = p4;
-        bf16x4 o4 = {f2bf(gv[0]), f2bf(gv[1]), f2bf(gv[2]), f2bf(gv[3])};
-        *(bf16x4*)((bf16*)a.out + o) = o4;
-    } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
-        const f32x4 r = *(const f32x4*)(a.resid + o);
-        *(f32x4*)((float*)a.out + o) = v + r;
-    } else if (EPI == OCN_EPI_DGELU) {
-        const bf16x4 p4 = *(const bf16x4*)(a.aux + o);
-        bf16x4 o4 = {f2bf(v[0] * bf2f(p4[0])), f2bf(v[1] * bf2f(p4[1])), f2bf(v[2] * bf2f(p4[2])), f2bf(v[3] * bf2f(p4[3]))};
-        *(bf16x4*)((bf16*)a.out + o) = o4;
-    } else {  // OCN_EPI_F32
-        *(f32x4*)((float*)a.out + o) = v;
-    }
-}
 
 template <int EPI>
 OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
@@ -98,94 +46,6 @@ OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
 // Geometry: workgroup tile BM x BN, WR x WC waves, each wave (BM/WR) x (BN/WC) = TI x TJ blocks of 32x32.
 //   <128,128,2,2>: 4 waves, 64 KiB ring, 2 workgroups / CU (small problems, ragged edges)
 //   <256,256,2,4>: 8 waves, 128 KiB ring, 1 workgroup / CU, wave tile 128x64 (less LDS traffic per MFMA)
-template <int EPI, int BM_, int BN_, int WR, int WC>
-__global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 * ((BM_ + BN_) * 256 <= 65536 ? 2 : 1)) / 256)
-void gemm_nt_kernel(GemmNtArgs a) {
-    constexpr int NW = WR * WC;
-    constexpr int TI = BM_ / WR / 32, TJ = BN_ / WC / 32;
-    constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = xcd_remap(blockIdx.x, a.ntiles);
-    const int m0 = (tile / a.tiles_n) * BM_, n0 = (tile % a.tiles_n) * BN_;
-    const int wm = wave / WC, wn = wave % WC;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int sw = swz_nt(lr);
-
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int a_row = (wm * TI * 32 + lr) * 128, b_row = (wn * TJ * 32 + lr) * 128;
-    const int nk = a.K / BK;
-
-    stage_nt<BM_, NW>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-    stage_nt<BN_, NW>(a.B, a.ldb, n0, a.N, 0, smem + A_BYTES, wave, lane);
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMA pieces of tile kt have landed
-        __syncthreads();                                  // everyone's have; everyone is done with tile kt-1
-        if (kt + 1 < nk) {
-            char* nxt = smem + ((kt + 1) & 1) * STAGE;
-            stage_nt<BM_, NW>(a.A, a.lda, m0, a.M, (kt + 1) * BK, nxt, wave, lane);
-            stage_nt<BN_, NW>(a.B, a.ldb, n0, a.N, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
-        }
-        const char* sA = cur;
-        const char* sB = cur + A_BYTES;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cpos = ((s * 2 + lh) ^ sw) << 4;
-            bf16x8 af[TI], bq[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(sA + a_row + i * 32 * 128 + cpos);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bq[j] = *(const bf16x8*)(sB + b_row + j * 32 * 128 + cpos);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(af[i], bq[j], acc[i][j]);
-        }
-    }
-    __syncthreads();  // all waves finished reading the ring; reuse it as per-wave C staging
-
-    // stage 32 x (TJ*32) fp32 slabs of the wave's sub-tile through its private LDS region so that global
-    // traffic is whole rows (full 128-/256-byte lines) for every epilogue operand
-    constexpr int TW = TJ * 32;                      // columns of the wave tile
-    float* sC = (float*)(smem + wave * (32 * TW * 4));  // <= 8 KiB per wave
-    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldc & 3) == 0);
-    constexpr int LPR = TW / 4;                      // lanes per row (16 for TW=64)
-    constexpr int RPI = 64 / LPR;                    // rows per iteration
-    const int col = (lane % LPR) * 4;
-    const int gn = n0 + wn * TW + col;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sC[mfma32_row(r, lane) * TW + j * 32 + lr] = acc[i][j][r];
-#pragma unroll 4
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
-            const int gm = m0 + (wm * TI + i) * 32 + row;
-            const f32x4 v = *(const f32x4*)(sC + row * TW + col);
-            if (gm < a.M) {
-                if (vec_ok) {
-                    if (gn < a.N) epilogue_store4<EPI>(a, gm, gn, v);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (gn + e < a.N) epilogue_store1<EPI>(a, gm, gn + e, v[e]);
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // NT "ring" kernel: 256x256 tile, 8 waves (2x4, wave tile 128x64), BK = 32, 4-stage LDS ring (4 x 32 KiB),
 // LDS-DMA prefetch three K-steps ahead with COUNTED vmcnt (never drained in the main loop), one raw
@@ -546,207 +406,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// TN "ring" kernel: dW tile 256 (n) x 256 (k), 8 waves (2 x 4, wave tile 128 x 64), 32 reduction rows per step,
-// 4-stage LDS ring with counted vmcnt like the NT ring kernel.  A stage holds [32 m][256 n] of A and [32 m][256 k]
-// of B as 512-byte rows; 16-byte chunks are XOR-swizzled by (row&3)<<2 so the transposing ds_read_b64_tr_b16 reads
-// (4 consecutive m-rows x 64 B per half-wave) are bank-conflict free.  Split over M fills the chip (one workgroup
-// per CU), so the main loop is long and the fp32-atomic epilogue is amortised.
-// ------------------------------------------------------------------------------------------------
-OCN_DEV bf16x8 frag_tn512(const char* sT, int cb, int s, int lane) {
-    const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
-    const int chunk = ((cb + g * 16) >> 3) + ((i & 3) >> 1);
-    const int p = chunk ^ ((i >> 2) << 2);
-    const int row = s * 16 + h * 8 + (i >> 2);
-    const char* base = sT + row * 512 + p * 16 + (i & 1) * 8;
-    const s16x4 lo = lds_read_tr16((const OCN_LDS void*)base);
-    const s16x4 hi = lds_read_tr16((const OCN_LDS void*)(base + 4 * 512));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(GemmTnArgs a) {
-    constexpr int HALF = 16384, STAGE = 32768;  // A part + B part
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 * STAGE = 128 KiB
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wid = xcd_remap(blockIdx.x, a.nwg);
-    const int ntile = a.tiles_n * a.tiles_k;
-    const int split = wid / ntile, tile = wid % ntile;
-    const int n0 = (tile / a.tiles_k) * 256, k0 = (tile % a.tiles_k) * 256;
-    const int m_begin = split * a.chunk;
-    const int m_end = min(a.M, m_begin + a.chunk);
-    const int wn = wave >> 2, wk = wave & 3;
-    const bool do_bias = (a.dbias != nullptr) && (k0 == 0);  // wave wk adds the column sums of A block i == wk
-    const int nk = (m_end - m_begin + 31) / 32;
-
-    // DMA: wave w moves rows {2w, 2w+1} and {16+2w, 17+2w} of each operand's [32][256] stage image
-    int rrow[2], ccol[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        rrow[j] = (wave + j * 8) * 2 + (lane >> 5);
-        ccol[j] = ((lane & 31) ^ ((rrow[j] & 3) << 2)) * 8;
-    }
-    const bf16* pa[2];
-    const bf16* pb[2];
-    bool va[2], vb[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        va[j] = (n0 + ccol[j]) < a.N;
-        vb[j] = (k0 + ccol[j]) < a.K;
-        pa[j] = a.A + (size_t)(m_begin + rrow[j]) * a.lda + n0 + ccol[j];
-        pb[j] = a.B + (size_t)(m_begin + rrow[j]) * a.ldb + k0 + ccol[j];
-    }
-    int mrow = m_begin;  // first row of the next stage to issue
-#define OCN_TN_DMA(SLOT)                                                                                         \
-    {                                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-            const bool inr = (mrow + rrow[j]) < m_end;                                                           \
-            glds16((inr && va[j]) ? (const void*)pa[j] : (const void*)g_zero16,                                  \
-                   (OCN_LDS void*)(smem + (SLOT) * STAGE + (wave + j * 8) * 1024));                              \
-            glds16((inr && vb[j]) ? (const void*)pb[j] : (const void*)g_zero16,                                  \
-                   (OCN_LDS void*)(smem + (SLOT) * STAGE + HALF + (wave + j * 8) * 1024));                       \
-            pa[j] += (size_t)32 * a.lda;                                                                         \
-            pb[j] += (size_t)32 * a.ldb;                                                                         \
-        }                                                                                                        \
-        mrow += 32;                                                                                              \
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-        if (s < nk) OCN_TN_DMA(s)
-
-    f32x16 acc[4][2], accb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-
-    bf16x8 a0[4], b0[2], a1[4], b1[2];
-#define OCN_TN_FRAGS(AF, BF, STG, S)                                                                             \
-    {                                                                                                            \
-        const char* sA_ = smem + ((STG)&3) * STAGE;                                                              \
-        const char* sB_ = sA_ + HALF;                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) AF[i] = frag_tn512(sA_, wn * 128 + i * 32, S, lane);        \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) BF[j] = frag_tn512(sB_, wk * 64 + j * 32, S, lane);         \
-    }
-#define OCN_TN_MFMA(AF, BF)                                                                                      \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
-            acc[i][j] = mfma32(AF[i], BF[j], acc[i][j]);                                                         \
-        if (do_bias) {                                                                                           \
-            if (wk == 0) accb = mfma32(AF[0], ones, accb);                                                       \
-            else if (wk == 1) accb = mfma32(AF[1], ones, accb);                                                  \
-            else if (wk == 2) accb = mfma32(AF[2], ones, accb);                                                  \
-            else accb = mfma32(AF[3], ones, accb);                                                               \
-        }                                                                                                        \
-    }
-#define OCN_TN_STEP(DMA, WAIT4)                                                                                  \
-    {                                                                                                            \
-        if (WAIT4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                              \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
-        __builtin_amdgcn_s_barrier();                                                                            \
-        OCN_TN_FRAGS(a1, b1, kt, 1);                                                                             \
-        if (DMA) OCN_TN_DMA((kt + 3) & 3)                                                                        \
-        OCN_TN_MFMA(a0, b0);                                                                                     \
-        const int nstg = kt + 1 < nk ? kt + 1 : kt;                                                              \
-        OCN_TN_FRAGS(a0, b0, nstg, 0);                                                                           \
-        OCN_TN_MFMA(a1, b1);                                                                                     \
-    }
-    if (nk > 0) {
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        OCN_TN_FRAGS(a0, b0, 0, 0);
-        int kt = 0;
-        for (; kt + 3 < nk; ++kt) OCN_TN_STEP(true, true)
-        for (; kt + 2 < nk; ++kt) OCN_TN_STEP(false, true)
-        for (; kt < nk; ++kt) OCN_TN_STEP(false, false)
-    }
-#undef OCN_TN_STEP
-#undef OCN_TN_MFMA
-#undef OCN_TN_FRAGS
-#undef OCN_TN_DMA
-    const int lr = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gk = k0 + wk * 64 + j * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gn = n0 + wn * 128 + i * 32 + mfma32_row(r, lane);
-                if (gn < a.N && gk < a.K) unsafeAtomicAdd(a.dW + (size_t)gn * a.ldw + gk, a.alpha * acc[i][j][r]);
-            }
-        }
-    if (do_bias && lr == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gn = n0 + wn * 128 + wk * 32 + mfma32_row(r, lane);
-            if (gn < a.N) unsafeAtomicAdd(a.dbias + gn, a.alpha * accb[r]);
-        }
-    }
-}
-
-template <int EPI, int BM_, int BN_, int WR, int WC>
-int launch_nt_geo(GemmNtArgs a, hipStream_t st) {
-    constexpr int LDS = 2 * (BM_ + BN_) * 128;
-    a.tiles_n = ocn_cdiv(a.N, BN_);
-    a.ntiles = ocn_cdiv(a.M, BM_) * a.tiles_n;
-    auto kern = gemm_nt_kernel<EPI, BM_, BN_, WR, WC>;
-    if (LDS > 65536) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr_set = true;
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(WR * WC * 64), LDS, st, a);
-    OCN_CHECK_LAUNCH("ocn_gemm_nt");
-    return OCN_OK;
-}
-
-int g_tn_variant = 0;  // 0 = auto, 1 = 128x128 two-stage, 2 = 256x256 ring, 3 = 256x256 hand-scheduled (gemm_tn5.hip)
+int g_tn_variant = 0;  // 0 = auto, 1 = general 128x128 kernel, 3 = 256x256 hand-scheduled (gemm_tn5.hip)
 int g_nt_ablate = 0;
-int g_nt_variant = 0;  // 0 = auto, 1 = 128x128, 2 = 256x256, 3 = 256x128, 4 = 256x256 4-stage ring (K % 32), 5 = persistent 256x256 (K % 128)
+int g_nt_variant = 0;  // 0 = auto, 4 = general 256x256 ring kernel (any M, N; K % 32), 5 = persistent 256x256 (gemm_nt5.hip; K % 128)
 
 template <int EPI>
 int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     int v = g_nt_variant;
-    if (v == 0) v = (a.M >= 1024 && a.N >= 192) ? 5 : 1;
-    if (v == 5) {  // persistent 256x256 kernel (gemm_nt5.hip); falls through when the shape does not fit it
+    if (v == 0) v = (a.M >= 1024 && a.N >= 192) ? 5 : 4;
+    if (v == 5) {  // persistent 256x256 kernel (gemm_nt5.hip); falls through to the general kernel when the shape does not fit it
         GemmNtArgs a5 = a;
         a5.ablate = g_nt_ablate;
         const int rc = ocn_launch_nt5(EPI, a5, st);
         if (rc <= 0) return rc;
-        v = (a.M >= 1024 && a.N >= 192) ? 4 : 1;
     }
-    if (a.K % 64) v = 4;  // the two-stage kernels step K by 64; the ring kernel by 32
-    if (v == 2) return launch_nt_geo<EPI, 256, 256, 2, 4>(a, st);
-    if (v == 3) return launch_nt_geo<EPI, 256, 128, 4, 2>(a, st);
-    if (v == 4) {
-        GemmNtArgs b = a;
-        b.ablate = g_nt_ablate;
-        b.tiles_n = ocn_cdiv(b.N, 256);
-        b.ntiles = ocn_cdiv(b.M, 256) * b.tiles_n;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(gemm_nt_ring_kernel<EPI>, dim3(b.ntiles), dim3(512), 131072, st, b);
-        OCN_CHECK_LAUNCH("ocn_gemm_nt");
-        return OCN_OK;
+    GemmNtArgs b = a;  // the one general kernel: ragged M / N (scalar epilogue when N % 4), K in steps of 32
+    b.ablate = g_nt_ablate;
+    b.tiles_n = ocn_cdiv(b.N, 256);
+    b.ntiles = ocn_cdiv(b.M, 256) * b.tiles_n;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set = true;
     }
-    return launch_nt_geo<EPI, 128, 128, 2, 2>(a, st);
+    hipLaunchKernelGGL(gemm_nt_ring_kernel<EPI>, dim3(b.ntiles), dim3(512), 131072, st, b);
+    OCN_CHECK_LAUNCH("ocn_gemm_nt");
+    return OCN_OK;
 }
 
 }  // namespace
@@ -814,28 +499,18 @@ extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int l
         if (rc < 0) ocn_set_error("ocn_gemm_tn_accum: launch failed");
         if (rc <= 0) return rc;
     }
-    const bool ring = (g_tn_variant == 2) || (g_tn_variant == 0 && big);
-    const int T = ring ? 256 : 128, RS = ring ? 32 : 64;
+    const int T = 128, RS = 64;  // the general kernel: 128x128 tile of dW, 64 reduction rows per step, M split to ~6 workgroups per CU
     a.tiles_n = ocn_cdiv(N, T);
     a.tiles_k = ocn_cdiv(K, T);
     const int ntile = a.tiles_n * a.tiles_k;
     const int msteps = ocn_cdiv(M, RS);
-    int splits = ring ? (256 / ntile > 0 ? 256 / ntile : 1) : ocn_cdiv(1536, ntile);  // ring: one workgroup per CU
+    int splits = ocn_cdiv(1536, ntile);
     if (splits > msteps) splits = msteps;
     if (splits < 1) splits = 1;
     a.chunk = ocn_cdiv(msteps, splits) * RS;
     splits = ocn_cdiv(M, a.chunk);
     a.nwg = splits * ntile;
-    if (ring) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(a.nwg), dim3(512), 131072, (hipStream_t)stream, a);
-    } else {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
-    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
     OCN_CHECK_LAUNCH("ocn_gemm_tn_accum");
     return OCN_OK;
 }

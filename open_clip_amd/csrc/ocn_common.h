@@ -68,19 +68,20 @@ OCN_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mf
 // row of accumulator register `reg` (0..15) of a 32x32 MFMA result for this lane; column = lane & 31
 OCN_DEV int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// erf-GELU (nn.GELU(), reference transformer.py:295-299) and its derivative.  erf by Abramowitz-Stegun
-// 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 resolution of the stored result) so the GEMM epilogues
-// stay off the VALU critical path: one v_exp_f32 + one v_rcp_f32 + 6 FMAs, shared between cdf and pdf.
+// erf-GELU (nn.GELU(), reference transformer.py:295-299) and its derivative.  The GEMM epilogue that applies it is VALU-issue bound with
+// every MFMA pipe idle (0.21 ms of the 1.18 ms c_fc GEMM at batch 4096: profiles/r02_nt6_trickled_epilogue_experiment.txt), so the
+// operation count is what matters: erfc by Abramowitz-Stegun 7.1.25 (three terms, |abs err| <= 2.5e-5 -- 1/80 of the bf16 resolution of
+// the stored result) with the 1/2 of Phi folded into the coefficients and the argument scaling folded into the constants:
+// 13 plain VALU operations + v_exp_f32 + v_rcp_f32 per element for gelu AND gelu' (shared parts evaluated once).
+//   h(x) = erfc(|x|/sqrt 2) / 2 = t (a1 + t (a2 + t a3)) / 2 * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt 2)
+//   Phi(x) = 1/2 + copysign(1/2 - h, x);   gelu = x Phi;   gelu' = Phi + x exp(-x^2/2) / sqrt(2 pi)
 OCN_DEV void gelu_parts(float x, float& cdf, float& e) {
-    const float u = fabsf(x) * 0.70710678118654752f;
-    e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);  // exp(-x^2/2)
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float q = p * t * e;               // 1 - erf(|u|)
-    cdf = x >= 0.f ? 1.0f - 0.5f * q : 0.5f * q;
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.47047f * 0.70710678118654752f, 1.0f));
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170f * (x * x));  // exp(-x^2/2)
+    float p = fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f);
+    p = fmaf(p, t, 0.5f * 0.3480242f);
+    const float h = p * t * e;
+    cdf = 0.5f + __builtin_copysignf(0.5f - h, x);
 }
 OCN_DEV float gelu_f(float x) {
     float cdf, e;

@@ -15,7 +15,7 @@ SHAPES_NT = [  # (name, M, N, K)
     ("txt qkv", Mt, 1536, 512), ("txt out", Mt, 512, 512), ("txt fc", Mt, 2048, 512), ("txt proj", Mt, 512, 2048),
 ]
 # variant ids may carry a developer ablation mask in bits 8+: 4 + 256*mask
-variants = [] if (len(sys.argv) > 1 and sys.argv[1] == "-") else [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3".split(","))]  # "-" = skip the NT sweep
+variants = [] if (len(sys.argv) > 1 and sys.argv[1] == "-") else [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "4,5".split(","))]  # "-" = skip the NT sweep
 epis = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3".split(","))]
 
 
@@ -73,8 +73,8 @@ for name, M, N, K in (SHAPES_NT if variants else []):
 print("sum ms per variant:", {v: round(t, 2) for v, t in tot.items()})
 _lib.call("ocn_set_gemm_variant", 0)
 
-print("TN (wgrad): variant 1 = 128x128 two-stage, 2 = 256x256 ring, 3 = 256x256 hand-scheduled (tn5)")
-for tv in (1, 2, 3):
+print("TN (wgrad): variant 1 = general 128x128, 3 = 256x256 hand-scheduled (tn5)")
+for tv in (1, 3):
     _lib.call("ocn_set_gemm_variant", tv << 4)
     g = torch.Generator().manual_seed(1)
     M, N, K = 3000, 640, 328
@@ -90,7 +90,7 @@ for name, M, N, K in SHAPES_NT:
     dw = torch.zeros(N, K, device=dev)
     db = torch.zeros(N, device=dev)
     row = []
-    for tv in (2, 3):
+    for tv in (1, 3):
         _lib.call("ocn_set_gemm_variant", tv << 4)
         ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
         ms0 = timeit(lambda: ops.gemm_tn_accum(a, b, dw, None))
