@@ -87,9 +87,9 @@ int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf
 int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, int M,
                       int C, ocn_stream_t stream);
-/* The same with the residual gradient exchanged as a (hi, lo) bf16 pair (value = hi + lo, 16 mantissa bits): dres may come as
- * dres_hi / dres_lo instead of fp32, and dx_lo (with dx_bf16 as its hi half) may replace dx_f32 -- 4 bytes per element instead
- * of 6 where the bf16 copy is needed anyway as the next GEMM's operand (hand-off between the two LayerNorm backwards of a block). */
+/* The same with the residual gradient exchanged in bf16: dres may come as dres_hi alone (bf16: the form the block backward uses --
+ * 10 instead of 16 bytes per element: dy 2 + x 4 + dres 2 in, dx 2 out, the bf16 dx being the next GEMM's operand anyway) or as a
+ * (hi, lo) pair (value = hi + lo, 16 mantissa bits) with dx_lo (next to dx_bf16 as its hi half) replacing dx_f32. */
 int ocn_layernorm_bwd_pair(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* dres, const void* dres_hi, const void* dres_lo, float* dx_f32, void* dx_bf16, void* dx_lo,
                            float* dw, float* db, int M, int C, ocn_stream_t stream);
@@ -139,9 +139,9 @@ int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* dtable, flo
 
 /* The same backward from SORTED ids (no per-occurrence atomics): sorted_tokens = the B*L token ids in ascending order, order[i] = the flat
  * row (b*L + l) of dx that sorted_tokens[i] came from (any stable or unstable sort; torch.sort on the device).  dtable must arrive ZEROED
- * (complete runs are stored, not added); dpos is accumulated into. */
-int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const float* dx, float* dtable, float* dpos, int B, int L,
-                               int C, int vocab, ocn_stream_t stream);
+ * (complete runs are stored, not added); dpos is accumulated into.  dx is fp32 or (dx_is_bf16) bf16 [B*L, C]. */
+int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable, float* dpos,
+                               int B, int L, int C, int vocab, ocn_stream_t stream);
 
 /* ---- pooling (transformer.py:786-787 'tok'; :941-944 'argmax') ---------------------------------
  * argmax_rows: idx[b] = first index of max(text[b,:]) (torch.argmax semantics)

@@ -34,7 +34,7 @@ SIGNATURES = {
     "ocn_embed_assemble_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_token_embed_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ocn_token_embed_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "ocn_token_embed_bwd_sorted": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ocn_token_embed_bwd_sorted": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],
     "ocn_gather_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ocn_scatter_rows": [_p, _p, _p, _p, _i, _i, _i, _p],

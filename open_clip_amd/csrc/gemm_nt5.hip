@@ -87,8 +87,14 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     // bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
     const int m_st = (a.ablate & 32) ? 0 : a.M, m_ld = (a.ablate & 128) ? 0 : a.M;
     const bool aux_is_out = (EPI == OCN_EPI_BIAS_GELU);
-    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m0, m_st, a.ldc, OUT_F32 ? 4 : 2);
-    const __amdgpu_buffer_rsrc_t r_aux = tile_rsrc(a.aux, m0, aux_is_out ? m_st : m_ld, a.ldc, 2);
+    // developer knob 0x80000: every store of this workgroup lands in ONE 64 KiB window (per workgroup, at the head of the output) that
+    // stays resident in L2 -- the stores are issued and acknowledged as usual but never have to wait for HBM: what the tile loop would
+    // cost if no operand wait ever sat behind a store acknowledgement (profiles/r02_nt6_trickled_epilogue_experiment.txt, finding (a))
+    const bool win = (a.ablate & 0x80000) != 0;
+    const unsigned omask = win ? 0xfff0u : ~0u;
+    const long m_win = win ? (long)((blockIdx.x * 65536L) / ((long)a.ldc * (OUT_F32 ? 4 : 2))) : m0;
+    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m_win, m_st, a.ldc, OUT_F32 ? 4 : 2);
+    const __amdgpu_buffer_rsrc_t r_aux = aux_is_out ? tile_rsrc(a.aux, m_win, m_st, a.ldc, 2) : tile_rsrc(a.aux, m0, m_ld, a.ldc, 2);
     const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 4);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
     // Bias is fetched ONCE, before any store of this tile is issued (a later load would have to wait behind the stores):
@@ -222,7 +228,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     for (int it = 0; it < 4; ++it) {
                         const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
                         const unsigned off = (unsigned)(row * a.ldc) * 2u + col_off;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off, 0, AUX & 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off & omask, 0, AUX & 2);
                     }
                 }
             }
@@ -269,13 +275,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             for (int it = 0; it < 4; ++it) {
                 const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
                 if (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u), 0, AUX & 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
                 } else if (EPI == OCN_EPI_DGELU) {
                     const f32x4 dg = ex[it];  // gelu'(pre-activation), saved by the forward epilogue
                     const bf16x4 o4 = {f2bf(v[0] * dg[0]), f2bf(v[1] * dg[1]), f2bf(v[2] * dg[2]), f2bf(v[3] * dg[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u), 0, AUX & 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u) & omask, 0, AUX & 2);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u), 0, AUX & 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
                 }
             }
         }

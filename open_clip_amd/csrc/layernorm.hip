@@ -100,10 +100,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 // the residual gradient is fetched together with x and dy (not after the row reductions): one memory
                 // round trip per row instead of two
                 if (dres) dr[i] = NT ? __builtin_nontemporal_load((const f32x4*)(dres + (size_t)row * C + c)) : *(const f32x4*)(dres + (size_t)row * C + c);
-                if (dres_hi) {  // residual gradient handed over as a (hi, lo) bf16 pair: value = hi + lo (16 mantissa bits)
+                if (dres_hi) {  // residual gradient handed over in bf16 (lo == NULL), or as a (hi, lo) pair: value = hi + lo (16 mantissa bits)
                     const bf16x4 h4 = *(const bf16x4*)(dres_hi + (size_t)row * C + c);
-                    const bf16x4 l4 = *(const bf16x4*)(dres_lo + (size_t)row * C + c);
-                    dr[i] = (f32x4){bf2f(h4[0]) + bf2f(l4[0]), bf2f(h4[1]) + bf2f(l4[1]), bf2f(h4[2]) + bf2f(l4[2]), bf2f(h4[3]) + bf2f(l4[3])};
+                    dr[i] = (f32x4){bf2f(h4[0]), bf2f(h4[1]), bf2f(h4[2]), bf2f(h4[3])};
+                    if (dres_lo) {
+                        const bf16x4 l4 = *(const bf16x4*)(dres_lo + (size_t)row * C + c);
+                        dr[i] += (f32x4){bf2f(l4[0]), bf2f(l4[1]), bf2f(l4[2]), bf2f(l4[3])};
+                    }
                 }
                 const f32x4 xv = NT ? __builtin_nontemporal_load((const f32x4*)(x + (size_t)row * C + c)) : *(const f32x4*)(x + (size_t)row * C + c);
                 f32x4 dy;
@@ -239,7 +242,7 @@ extern "C" int ocn_layernorm_bwd_pair(const void* dy, int dy_is_f32, const float
                                       const float* rstd, const float* dres, const void* dres_hi_, const void* dres_lo_, float* dx_f32,
                                       void* dx_bf16, void* dx_lo_, float* dw, float* db, int M, int C, ocn_stream_t stream) {
     OCN_CHECK_ARG(dy && x && w && mean && rstd && dw && db && (dx_f32 || dx_bf16), "ocn_layernorm_bwd: null operand");
-    OCN_CHECK_ARG((dres_hi_ == nullptr) == (dres_lo_ == nullptr) && !(dres && dres_hi_), "ocn_layernorm_bwd_pair: dres is fp32 OR a (hi, lo) pair");
+    OCN_CHECK_ARG(!(dres_lo_ && !dres_hi_) && !(dres && dres_hi_), "ocn_layernorm_bwd_pair: dres is fp32 OR bf16 (hi alone) OR a (hi, lo) pair");
     OCN_CHECK_ARG(!dx_lo_ || dx_bf16, "ocn_layernorm_bwd_pair: dx_lo needs dx_bf16 (its hi half)");
     const bf16* dres_hi = (const bf16*)dres_hi_;
     const bf16* dres_lo = (const bf16*)dres_lo_;

@@ -110,9 +110,11 @@ def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dres_pair=None, want_pair=False):
-    """``dres_pair`` = (hi, lo) bf16 tensors instead of an fp32 ``dres``; ``want_pair`` returns (None, hi, lo) instead of
-    (dx32, dx16): the residual gradient as a bf16 pair (see ocn_layernorm_bwd_pair)."""
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dres_pair=None, want_pair=False, dres16=None):
+    """``dres16`` = the residual gradient in bf16 (instead of an fp32 ``dres``); ``dres_pair`` = (hi, lo) bf16 tensors;
+    ``want_pair`` returns (None, hi, lo) instead of (dx32, dx16): the residual gradient as a bf16 pair (see ocn_layernorm_bwd_pair)."""
+    if dres16 is not None:
+        dres_pair = (dres16, None)
     M, C = x.shape
     is32 = dy.dtype == F32
     dx32 = empty((M, C), F32, x) if (want_f32 and not want_pair) else None
@@ -210,8 +212,9 @@ def token_embed_bwd_sorted(text, dx, dtable, dpos):
     B, L = text.shape
     vocab, C = dtable.shape
     keys, order = torch.sort(text.reshape(-1))
-    _lib.call("ocn_token_embed_bwd_sorted", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"), _chk(dx, F32, "dx"),
-              _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
+    is16 = dx.dtype == BF16
+    _lib.call("ocn_token_embed_bwd_sorted", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"),
+              _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
 
 
 def argmax_rows(text):

