@@ -72,16 +72,17 @@ class _WeightCache:
 # tensor (autograd summed two branches, a hook replaced the gradient, ...) finds no attribute and casts.
 # ------------------------------------------------------------------------------------------------------
 #
-# Between the blocks of a tower the bf16 twin IS the gradient (OCN_GRAD_STREAM=fp32 restores the fp32 + twin form): the LayerNorm
-# backward that ends a block's backward writes only the bf16 gradient (the next block's GEMM operand AND the residual term its
-# LayerNorm backwards add in: 10 bytes per element and LayerNorm backward instead of 16), and what autograd is handed as the
-# "official" fp32 gradient is a NaN scalar expanded to the right shape (stride 0, no memory).  Every consumer in this file takes the
-# twin; anything that touched the placeholder instead would either fail here (``_take_twin``: "hand-off lost") or produce NaN --
-# never a silently wrong number.  Accumulating 24 residual-gradient additions with one bf16 rounding each adds ~5e-3 relative to
-# gradients whose bf16-operand error is 1-4e-2 (tests/test_model_gpu.py tolerances unchanged).
+# OCN_GRAD_STREAM=bf16 (experiment, OFF by default): between the blocks of a tower the bf16 twin IS the gradient -- the LayerNorm
+# backward that ends a block's backward then writes only the bf16 gradient (the next block's GEMM operand AND the residual term its
+# LayerNorm backwards add in: 10 bytes per element instead of 16), and what autograd is handed as the "official" fp32 gradient is a
+# NaN scalar expanded to the right shape (stride 0, no memory); every consumer in this file takes the twin, anything else that touched
+# the placeholder would fail loudly (``_take_twin``) or produce NaN.  Measured on the MI355X (profiles/r02_experiments.txt): -1.7 ms
+# of 233 (the LayerNorm backward is not bandwidth-bound with 8-byte accesses per lane) while 24 residual-gradient additions rounded
+# to bf16 raise the error of the early image blocks' bias / class-embedding gradients from 2e-2 to 4.5-5.4e-2 (above the stated
+# 5e-2) -- so the fp32 stream stays.
 # ------------------------------------------------------------------------------------------------------
 TWIN_STATS = {"hit": 0, "miss": 0}  # how often the hand-off was taken (tests assert it is)
-_BF16_GRAD_STREAM = __import__("os").environ.get("OCN_GRAD_STREAM", "bf16") != "fp32"
+_BF16_GRAD_STREAM = __import__("os").environ.get("OCN_GRAD_STREAM", "fp32") == "bf16"
 
 
 def _publish_twin(g32, g16):
