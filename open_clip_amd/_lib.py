@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libopenclip_hip.so")
+LIB_PATH = os.environ.get("OCN_LIB_PATH") or os.path.join(_HERE, "libopenclip_hip.so")  # OCN_LIB_PATH: developer builds (A/B of compile-time experiments)
 
 _p, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 

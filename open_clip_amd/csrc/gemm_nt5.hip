@@ -443,6 +443,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+// OCN_PRIO_MODE (compile-time experiment, profiles/r02_setprio_experiment.txt): 1 = s_setprio 1 around every MFMA group of the main loop,
+// 2 = static priority for the second-dispatched half of the workgroup (waves 4..7), 3 = both
+#ifndef OCN_PRIO_MODE
+#define OCN_PRIO_MODE 0
+#endif
+#if (OCN_PRIO_MODE & 1)
+#define PRIO_ON() __builtin_amdgcn_s_setprio(1);
+#define PRIO_OFF() __builtin_amdgcn_s_setprio(0);
+#else
+#define PRIO_ON()
+#define PRIO_OFF()
+#endif
 #define MM(HA, FA, KS)                                                        \
     acc[HA][0][0] = mfma32(fb[0][KS], FA[0], acc[HA][0][0]);                  \
     acc[HA][0][1] = mfma32(fb[1][KS], FA[0], acc[HA][0][1]);                  \
@@ -460,33 +472,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         __builtin_amdgcn_s_barrier();                                                             \
         SB();                                                                                     \
         RD_A(fa[1], 1, 0, P) RD_B(1, P)                                                           \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         acc[0][0][0] = mfma32(fb[0][0], fa[0][0], acc[0][0][0]);                                  \
         acc[0][0][1] = mfma32(fb[1][0], fa[0][0], acc[0][0][1]);                                  \
         DMA_A1(0, (P) ^ 1)                                                                        \
         acc[0][1][0] = mfma32(fb[0][0], fa[0][1], acc[0][1][0]);                                  \
         DMA_A1(1, (P) ^ 1)                                                                        \
         acc[0][1][1] = mfma32(fb[1][0], fa[0][1], acc[0][1][1]);                                  \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 2, 0, P) RD_B(2, P)                                                           \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         MM(0, fa[1], 1)                                                                           \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[1], 3, 0, P) RD_B(3, P)                                                           \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         MM(0, fa[0], 2)                                                                           \
         adv_a1();                                                                                 \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 0, 1, P)                                                                      \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         MM(0, fa[1], 3)                                                                           \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         /* ---- odd phase: A1 x (B0, B1), B fragments from registers ---- */                      \
         if (!(SKIP)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                             \
         __builtin_amdgcn_s_barrier();                                                             \
         SB();                                                                                     \
         RD_A(fa[1], 1, 1, P)                                                                      \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         acc[1][0][0] = mfma32(fb[0][0], fa[0][0], acc[1][0][0]);                                  \
         DMA_A0(0, P)                                                                              \
         acc[1][0][1] = mfma32(fb[1][0], fa[0][0], acc[1][0][1]);                                  \
@@ -495,32 +507,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         DMA_B0(0, P)                                                                              \
         acc[1][1][1] = mfma32(fb[1][0], fa[0][1], acc[1][1][1]);                                  \
         DMA_B0(1, P)                                                                              \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 2, 1, P)                                                                      \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         acc[1][0][0] = mfma32(fb[0][1], fa[1][0], acc[1][0][0]);                                  \
         DMA_B1(0, P)                                                                              \
         acc[1][0][1] = mfma32(fb[1][1], fa[1][0], acc[1][0][1]);                                  \
         DMA_B1(1, P)                                                                              \
         acc[1][1][0] = mfma32(fb[0][1], fa[1][1], acc[1][1][0]);                                  \
         acc[1][1][1] = mfma32(fb[1][1], fa[1][1], acc[1][1][1]);                                  \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[1], 3, 1, P)                                                                      \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         MM(1, fa[0], 2)                                                                           \
         adv_ab();                                                                                 \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         /* first fragments of the next K-tile (ring parity P^1; published by this phase's barrier) */ \
         if (!(LAST)) { RD_A(fa[0], 0, 0, (P) ^ 1) RD_B(0, (P) ^ 1) }                              \
-        SB();                                                                                     \
+        SB(); PRIO_ON()                                                                                     \
         MM(1, fa[1], 3)                                                                           \
-        SB(); LGKM0(); SB();                                                                      \
+        PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
     }
 
     const unsigned stg = lds_base + RING_BYTES + wave * STG_BYTES;
     long long* dbg = nullptr;
     if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = g_nt5_trace + (blockIdx.x ? 512 : 0);
 #define STAMP(IDX) if (DBG && dbg && i < 8) dbg[i * 8 + (IDX)] = wall_clock64();
+#if (OCN_PRIO_MODE & 2)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int i = 0; i < my_tiles; ++i) {
         STAMP(0)
 #pragma unroll

@@ -167,6 +167,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     DMA_A(0, 2) DMA_A(1, 2) DMA_B(0, 2) DMA_B(1, 2)
     DMA_ADV()
     FragSet X, Y;
+#if (OCN_PRIO_MODE & 2)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
@@ -174,6 +177,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     WAIT_SET(X);
     SB();
 
+// OCN_PRIO_MODE (compile-time experiment, profiles/r02_setprio_experiment.txt): 1 = s_setprio 1 over the MFMA work of a step,
+// 2 = static priority for waves 4..7, 3 = both
+#ifndef OCN_PRIO_MODE
+#define OCN_PRIO_MODE 0
+#endif
+#if (OCN_PRIO_MODE & 1)
+#define PRIO_ON() __builtin_amdgcn_s_setprio(1);
+#define PRIO_OFF() __builtin_amdgcn_s_setprio(0);
+#else
+#define PRIO_ON()
+#define PRIO_OFF()
+#endif
 #define MM(S, IB, JB) acc[IB][JB] = mfma32(cat((S).a[IB]), cat((S).b[JB]), acc[IB][JB]);
 #define STEP(SLOT)                                                                                   \
     {                                                                                                \
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
         __builtin_amdgcn_s_barrier();                                                                \
         SB();                                                                                        \
         READ_SET(Y, SLOT, 1)                                                                         \
-        SB();                                                                                        \
+        SB(); PRIO_ON()                                                                              \
         const bool bias_now = BIAS && (bc == 0);                                                     \
         MM(X, 0, 0) MM(X, 0, 1)                                                                      \
         SB();                                                                                        \
@@ -199,17 +214,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
         SB();                                                                                        \
         DMA_B(1, ((SLOT) + 3) & 3)                                                                   \
         if (bias_now) accb = mfma32(cat(X.a[0]), ones, accb);                                        \
-        SB();                                                                                        \
+        PRIO_OFF() SB();                                                                             \
         WAIT_SET(Y);                                                                                 \
         SB();                                                                                        \
         READ_SET(X, ((SLOT) + 1) & 3, 0)                                                             \
-        SB();                                                                                        \
+        SB(); PRIO_ON()                                                                              \
         MM(Y, 0, 0) MM(Y, 0, 1) MM(Y, 1, 0) MM(Y, 1, 1)                                              \
         DMA_ADV()                                                                                    \
         MM(Y, 2, 0) MM(Y, 2, 1) MM(Y, 3, 0) MM(Y, 3, 1)                                              \
         if (bias_now) accb = mfma32(cat(Y.a[0]), ones, accb);                                        \
         if (BIAS) bc = (bc == 0 ? a.tiles_k : bc) - 1;                                               \
-        SB();                                                                                        \
+        PRIO_OFF() SB();                                                                             \
         WAIT_SET(X);                                                                                 \
         SB();                                                                                        \
     }
