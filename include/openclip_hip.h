@@ -199,6 +199,20 @@ int ocn_adamw_multi(const void* entries, const void* chunks, int n_chunks, float
                     const float* gnorm_sq, float max_norm, ocn_stream_t stream);
 int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, ocn_stream_t stream);
 
+/* ---- collectives (loss.py:23-54 gather_features and its backward) ------------------
+ * Direct RCCL calls on the caller's stream (RCCL is bound at run time from the librccl.so the process has loaded; no link-time
+ * dependency).  One process per GPU.  ocn_comm_unique_id: rank 0 makes the 128-byte id, the caller distributes it (any
+ * side channel); ocn_comm_init: every rank, collectively.  dtype: 0 = fp32, 1 = bf16.  Counts are ELEMENTS per rank.
+ *   allgather:           recv [world * count] = concat_r send_r [count]             (the packed [B, 2E] feature exchange)
+ *   reduce_scatter_sum:  recv [count] = (sum_r send_r [world * count]) [rank slice]   (backward of the gather, loss.py:23-26)
+ *   allreduce_sum:       buf [count] = sum_r buf_r, in place                         (row-sharded loss scalars, gradient buckets) */
+int ocn_comm_unique_id(void* id_out_128);
+int ocn_comm_init(const void* id_128, int rank, int world, void** comm_out);
+int ocn_comm_destroy(void* comm);
+int ocn_comm_allgather(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, ocn_stream_t stream);
+int ocn_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, ocn_stream_t stream);
+int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream);
+
 /* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
 int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,
                      ocn_stream_t stream);

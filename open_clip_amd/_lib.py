@@ -47,6 +47,12 @@ SIGNATURES = {
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
     "ocn_adamw_multi": [_p, _p, _i, _f, _f, _f, _p, _f, _p],
     "ocn_sumsq_multi": [_p, _p, _i, _p, _p],
+    "ocn_comm_unique_id": [_p],
+    "ocn_comm_init": [_p, _i, _i, _p],
+    "ocn_comm_destroy": [_p],
+    "ocn_comm_allgather": [_p, _p, _p, _l, _i, _p],
+    "ocn_comm_reduce_scatter_sum": [_p, _p, _p, _l, _i, _p],
+    "ocn_comm_allreduce_sum": [_p, _p, _l, _i, _p],
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }

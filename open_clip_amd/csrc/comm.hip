@@ -1,0 +1,115 @@
+// Collectives of the hot path behind the C ABI (SURVEY.md 8b "Exports needed": ocn_comm_*): the feature all-gather of
+// gather_features (reference src/open_clip/loss.py:29-54), its reduce-scatter backward (:23-26) and a gradient all-reduce, as direct
+// RCCL calls on the caller's stream -- no process-group object, no Python in between.  RCCL is bound at run time with dlopen /
+// dlsym (the library torch has already loaded: its bundled librccl.so), so libopenclip_hip.so carries no link-time dependency on it.
+// One process per GPU; a communicator is created from a 128-byte unique id that rank 0 makes and the caller distributes (the
+// reference broadcasts such things with distributed.broadcast_object, open_clip_train/distributed.py:186-193).
+#include "ocn_common.h"
+
+#include <dlfcn.h>
+#include <string.h>
+
+namespace {
+
+typedef struct { char internal[128]; } UniqueId;  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* Comm;                               // ncclComm_t
+enum { kSum = 0, kFloat32 = 7, kBfloat16 = 9 };   // ncclSum, ncclFloat32, ncclBfloat16 (rccl.h)
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy torch.distributed has loaded, if any
+        if (!r.handle) r.handle = dlopen(name, RTLD_NOW);
+        if (r.handle) break;
+    }
+    if (!r.handle) return nullptr;
+    *(void**)&r.GetUniqueId = dlsym(r.handle, "ncclGetUniqueId");
+    *(void**)&r.CommInitRank = dlsym(r.handle, "ncclCommInitRank");
+    *(void**)&r.CommDestroy = dlsym(r.handle, "ncclCommDestroy");
+    *(void**)&r.AllGather = dlsym(r.handle, "ncclAllGather");
+    *(void**)&r.ReduceScatter = dlsym(r.handle, "ncclReduceScatter");
+    *(void**)&r.AllReduce = dlsym(r.handle, "ncclAllReduce");
+    *(void**)&r.GetErrorString = dlsym(r.handle, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.ReduceScatter || !r.AllReduce) r.handle = nullptr;
+    return r.handle ? &r : nullptr;
+}
+
+int dtype_of(int d) { return d == 1 ? kBfloat16 : kFloat32; }
+
+#define OCN_RCCL(call, what)                                                                          \
+    do {                                                                                              \
+        const int rc__ = (call);                                                                      \
+        if (rc__ != 0) {                                                                              \
+            ocn_set_error("%s: RCCL error %d (%s)", what, rc__, R->GetErrorString ? R->GetErrorString(rc__) : "?"); \
+            return OCN_ERR_LAUNCH;                                                                    \
+        }                                                                                             \
+    } while (0)
+
+}  // namespace
+
+extern "C" int ocn_comm_unique_id(void* id_out_128) {
+    OCN_CHECK_ARG(id_out_128, "ocn_comm_unique_id: null output");
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R, "ocn_comm_unique_id: librccl.so could not be loaded");
+    UniqueId id;
+    OCN_RCCL(R->GetUniqueId(&id), "ocn_comm_unique_id");
+    memcpy(id_out_128, &id, sizeof(id));
+    return OCN_OK;
+}
+
+extern "C" int ocn_comm_init(const void* id_128, int rank, int world, void** comm_out) {
+    OCN_CHECK_ARG(id_128 && comm_out && world > 0 && rank >= 0 && rank < world, "ocn_comm_init: bad arguments (rank %d of %d)", rank, world);
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R, "ocn_comm_init: librccl.so could not be loaded");
+    UniqueId id;
+    memcpy(&id, id_128, sizeof(id));
+    Comm c = nullptr;
+    OCN_RCCL(R->CommInitRank(&c, world, id, rank), "ocn_comm_init");
+    *comm_out = c;
+    return OCN_OK;
+}
+
+extern "C" int ocn_comm_destroy(void* comm) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm, "ocn_comm_destroy: bad arguments");
+    OCN_RCCL(R->CommDestroy((Comm)comm), "ocn_comm_destroy");
+    return OCN_OK;
+}
+
+// recv [world * count] = concatenation over ranks of send [count]   (loss.py:43-46: the packed [B, 2E] feature all-gather)
+extern "C" int ocn_comm_allgather(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, ocn_stream_t stream) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm && send && recv && count_per_rank > 0, "ocn_comm_allgather: bad arguments");
+    OCN_RCCL(R->AllGather(send, recv, (size_t)count_per_rank, dtype_of(dtype), (Comm)comm, (hipStream_t)stream), "ocn_comm_allgather");
+    return OCN_OK;
+}
+
+// recv [count] = this rank's slice of the element-wise sum over ranks of send [world * count]   (loss.py:23-26: backward of the gather)
+extern "C" int ocn_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, ocn_stream_t stream) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm && send && recv && count_per_rank > 0, "ocn_comm_reduce_scatter_sum: bad arguments");
+    OCN_RCCL(R->ReduceScatter(send, recv, (size_t)count_per_rank, dtype_of(dtype), kSum, (Comm)comm, (hipStream_t)stream), "ocn_comm_reduce_scatter_sum");
+    return OCN_OK;
+}
+
+// buf [count] = element-wise sum over ranks, in place   (the scalar sums of the row-sharded loss; gradient buckets)
+extern "C" int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm && buf && count > 0, "ocn_comm_allreduce_sum: bad arguments");
+    OCN_RCCL(R->AllReduce(buf, buf, (size_t)count, dtype_of(dtype), kSum, (Comm)comm, (hipStream_t)stream), "ocn_comm_allreduce_sum");
+    return OCN_OK;
+}

@@ -49,10 +49,12 @@ def _bf16_transposed(x, npad):
     return out
 
 
-def _reduce_scatter_sum(out, inp):
-    """reduce-scatter(sum) of inp [W*B, X] into out [B, X]; RCCL does it natively, gloo (CPU tests) lacks the
-    collective, so fall back to all-reduce + slice there (same result)."""
-    if dist.get_backend() == "gloo":
+def _reduce_scatter_sum(out, inp, comm=None):
+    """reduce-scatter(sum) of inp [W*B, X] into out [B, X]; RCCL does it natively (through ``comm`` = a NativeComm, or the process
+    group), gloo (CPU tests) lacks the collective, so fall back to all-reduce + slice there (same result)."""
+    if comm is not None:
+        comm.reduce_scatter_sum(out, inp)
+    elif dist.get_backend() == "gloo":
         tmp = inp.clone()
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
         r, b = dist.get_rank(), out.shape[0]
@@ -121,6 +123,20 @@ class _PairTerm:
         return out[:self.N, :self.E]
 
 
+def _all_gather(out, inp, comm=None):
+    if comm is not None:
+        comm.all_gather_into_tensor(out, inp)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def _all_reduce_sum(t, comm=None):
+    if comm is not None:
+        comm.all_reduce_sum(t)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def _device_scalar(t, dev):
     """1-element fp32 device tensor with the value of ``t`` (a 0-d parameter / tensor); no host read"""
     return t.detach().to(device=dev, dtype=F32).reshape(1)
@@ -128,7 +144,7 @@ def _device_scalar(t, dev):
 
 class _ClipLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False):
+    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False, comm=None):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         dev = I.device
         s = _device_scalar(logit_scale, dev)  # stays on the device: no host synchronisation inside the step
@@ -137,7 +153,7 @@ class _ClipLossFn(torch.autograd.Function):
         if world_size > 1:
             packed = torch.cat([I, T], dim=1)
             allp = torch.empty(world_size * B, 2 * E, dtype=F32, device=dev)
-            dist.all_gather_into_tensor(allp, packed)
+            _all_gather(allp, packed, comm)
             I_all, T_all = allp[:, :E].contiguous(), allp[:, E:].contiguous()
         if world_size == 1:
             # loss.py:109-110: li = s I T^T, lt = s T I^T ; labels arange(B)
@@ -173,10 +189,10 @@ class _ClipLossFn(torch.autograd.Function):
             dI, dT = ti.dX(), tt.dX()
             through_cols = torch.cat([tt.dY(), ti.dY()], dim=1).contiguous()  # [N, 2E]: d I_all | d T_all from my rows
             mine = torch.empty(B, 2 * E, dtype=F32, device=dev)
-            _reduce_scatter_sum(mine, through_cols)
+            _reduce_scatter_sum(mine, through_cols, comm)
             dI = dI + mine[:, :E]
             dT = dT + mine[:, E:]
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            _all_reduce_sum(acc, comm)
             d_all = None
         else:
             # loss.py:106-107: li = s I_all T_all^T, lt = li^T ; labels arange(N)
@@ -197,19 +213,19 @@ class _ClipLossFn(torch.autograd.Function):
                 d_all = None
         acc[1:2].div_(s)  # d loss / d logit_scale = sum(G * logits) / s
         ctx.save_for_backward(dI, dT, acc, d_all)
-        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype)
+        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype, comm)
         return acc[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         dI, dT, acc, d_all = ctx.saved_tensors
-        world_size, B, E, idt, tdt = ctx.meta
+        world_size, B, E, idt, tdt, comm = ctx.meta
         if d_all is not None:  # backward of the differentiable all-gather = reduce-scatter(sum) (loss.py:23-26)
             mine = torch.empty(B, 2 * E, dtype=F32, device=dI.device)
-            _reduce_scatter_sum(mine, d_all)
+            _reduce_scatter_sum(mine, d_all, comm)
             dI = dI + mine[:, :E]
             dT = dT + mine[:, E:]
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None, None
 
 
 PairTerm = _PairTerm  # the one seam tests replace to exercise the collective plumbing on CPU/gloo
@@ -219,8 +235,9 @@ class NativeClipLoss(nn.Module):
     """``open_clip.loss.ClipLoss`` (loss.py:57-141) on the HIP path.  ``cache_labels`` is accepted for
     signature parity; labels are an arange predicate inside the kernel (nothing to cache)."""
 
-    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, row_sharded=False):
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, row_sharded=False, comm=None):
         super().__init__()
+        self.comm = comm  # optional open_clip_amd.comm.NativeComm: the collectives through the C ABI instead of torch.distributed
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size = rank, world_size
         # native extension (not a reference argument): evaluate the global loss (local_loss=False, gather_with_grad=False)
@@ -231,13 +248,13 @@ class NativeClipLoss(nn.Module):
         # loss.py:111-113 adds logit_bias to both logit matrices; a constant added to every logit of a row changes neither the
         # softmax nor the cross-entropy, so it is accepted and contributes nothing (its gradient is exactly zero there as well)
         loss = _ClipLossFn.apply(image_features, text_features, logit_scale, self.local_loss, self.gather_with_grad,
-                                 self.rank, self.world_size, self.row_sharded)
+                                 self.rank, self.world_size, self.row_sharded, self.comm)
         return {"contrastive_loss": loss} if output_dict else loss
 
 
 class _SigLipLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size):
+    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size, comm=None):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         dev = I.device
         s, b = _device_scalar(logit_scale, dev), _device_scalar(logit_bias, dev)
@@ -245,7 +262,7 @@ class _SigLipLossFn(torch.autograd.Function):
         acc = torch.zeros(3, dtype=F32, device=dev)  # loss, dscale, dbias
         if world_size > 1:
             T_all = torch.empty(world_size * B, E, dtype=F32, device=dev)
-            dist.all_gather_into_tensor(T_all, T)
+            _all_gather(T_all, T, comm)
         else:
             T_all = T
         # loss.py:406-489: local chunk with positives on the diagonal, every other rank's chunk negative-only.
@@ -256,19 +273,19 @@ class _SigLipLossFn(torch.autograd.Function):
         dI = term.dX()
         dT_all = term.dY().contiguous()
         ctx.save_for_backward(dI, dT_all, acc)
-        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype)
+        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype, comm)
         return acc[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         dI, dT_all, acc = ctx.saved_tensors
-        world_size, B, E, idt, tdt = ctx.meta
+        world_size, B, E, idt, tdt, comm = ctx.meta
         if world_size > 1:  # reverse of the neighbour exchange (loss.py:279-311): every chunk's grad returns to its owner
             dT = torch.empty(B, E, dtype=F32, device=dI.device)
-            _reduce_scatter_sum(dT, dT_all)
+            _reduce_scatter_sum(dT, dT_all, comm)
         else:
             dT = dT_all
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None, None
 
 
 class NativeSigLipLoss(nn.Module):
@@ -276,12 +293,13 @@ class NativeSigLipLoss(nn.Module):
     replaced by one all-gather of the text features (xGMI is fully connected; the payload is 2 MiB per rank)
     and one reduce-scatter in the backward -- the loss value and every gradient are identical."""
 
-    def __init__(self, cache_labels=False, rank=0, world_size=1, dist_impl=None, chunk_size=0):
+    def __init__(self, cache_labels=False, rank=0, world_size=1, dist_impl=None, chunk_size=0, comm=None):
         super().__init__()
+        self.comm = comm
         self.cache_labels, self.rank, self.world_size = cache_labels, rank, world_size
         self.dist_impl = dist_impl or "bidir"
         self.chunk_size = chunk_size
 
     def forward(self, image_features, text_features, logit_scale, logit_bias, output_dict=False):
-        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size)
+        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size, self.comm)
         return {"contrastive_loss": loss} if output_dict else loss

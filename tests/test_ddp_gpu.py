@@ -136,3 +136,23 @@ def test_rccl_process_group_runs_the_loss_collectives(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_nccl_one_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     assert open(os.path.join(str(tmp_path), "ok.txt")).read() == "1"
+
+
+def test_native_comm_one_rank_collectives_through_the_c_abi():
+    """ocn_comm_* (RCCL bound at run time behind the C ABI) with a ONE-rank communicator on the test box's GPU: all-gather,
+    reduce-scatter and all-reduce must be identities, in fp32 and bf16 (more ranks need more GPUs: RCCL refuses two per device)"""
+    from open_clip_amd.comm import NativeComm
+    torch.cuda.set_device(0)
+    comm = NativeComm(NativeComm.make_unique_id(), 0, 1)
+    g = torch.Generator().manual_seed(9)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(64, 48, generator=g).to(dt).cuda()
+        out = torch.empty_like(x)
+        comm.all_gather_into_tensor(out, x)
+        rs = torch.empty_like(x)
+        comm.reduce_scatter_sum(rs, x)
+        ar = x.clone()
+        comm.all_reduce_sum(ar)
+        torch.cuda.synchronize()
+        assert torch.equal(out, x) and torch.equal(rs, x) and torch.equal(ar, x), dt
+    comm.close()

@@ -3,7 +3,9 @@
   (2) the CPU oracle (oracle/clip_oracle.py) on fresh seeded inputs.
 Stated tolerance (bf16 operands / fp32 accumulation, fp32 residual stream, vs the fp32 CPU reference):
   features max-abs <= 4e-3 (unit-norm vectors), loss |d| <= 2e-2, logits max-abs <= 0.15 (scale up to 100),
-  parameter-gradient rel-L2 <= 5e-2 per tensor (<= 0.12 for tensors whose gradient norm is < 1e-3 of the largest).
+  parameter-gradient rel-L2 <= 3.5e-2 for weight matrices / embeddings (measured <= 2.6e-2, profiles/r02_parity_report.txt), <= 5e-2 for
+  1-D tensors (biases, LayerNorm affine: column sums with cancellation, measured <= 3.9e-2), <= 0.12 for tensors whose gradient norm
+  is < 1e-3 of the largest.
 Measured values are appended to gpurun_out/parity_report.txt."""
 import numpy as np
 import pytest
@@ -17,6 +19,13 @@ from tests.test_kernels_gpu import _report
 pytestmark = pytest.mark.gpu
 
 FEAT_TOL, LOSS_TOL, GRAD_TOL, GRAD_TOL_SMALL = 4e-3, 2e-2, 5e-2, 0.12
+GRAD_TOL_MATRIX = 3.5e-2
+
+
+def _grad_tol(ref_norm, gmax, ndim):
+    if ref_norm < 1e-3 * gmax:
+        return GRAD_TOL_SMALL
+    return GRAD_TOL_MATRIX if ndim >= 2 else GRAD_TOL
 
 
 def _build(cfg, state, siglip=False, **kw):
@@ -55,8 +64,7 @@ def _compare(tag, g, model, out, loss):
     assert fi <= FEAT_TOL and ft <= FEAT_TOL, (fi, ft)
     assert dl <= LOSS_TOL, dl
     for rel, k, n in worst:
-        tol = GRAD_TOL if n >= 1e-3 * gmax else GRAD_TOL_SMALL
-        assert rel <= tol, (k, rel, n)
+        assert rel <= _grad_tol(n, gmax, grads[k].ndim), (k, rel, n)
 
 
 @pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True)])
@@ -103,7 +111,7 @@ def test_against_cpu_oracle(cfg_name, B, ckpt):
     for k, p in model.named_parameters():
         ref = grads[k]
         rel = float((p.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
-        tol = GRAD_TOL if float(ref.norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        tol = _grad_tol(float(ref.norm()), gmax, ref.ndim)
         if rel > tol * 0.5:
             _report(f"oracle[{cfg_name}]:   grad rel_l2={rel:.3e} |g|={float(ref.norm()):.3e} {k}")
         assert rel <= tol, (k, rel)
@@ -210,7 +218,7 @@ def test_vitl14_grad_checkpointed_step_against_cpu_oracle():
     for k in keys:
         ref = grads[k]
         rel = float((named[k].grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
-        tol = GRAD_TOL if float(ref.norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        tol = _grad_tol(float(ref.norm()), gmax, ref.ndim)
         _report(f"oracle[ViT-L-14]:   grad rel_l2={rel:.3e} |g|={float(ref.norm()):.3e} {k}")
         assert rel <= tol, (k, rel)
 
@@ -434,7 +442,7 @@ def test_vith14_siglip_full_size_against_cpu_oracle_and_loss_after_one_update():
     for k in keys:
         ref = grads[k]
         rel = float((named[k].grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
-        tol = GRAD_TOL if float(ref.norm()) >= 1e-3 * gmax else GRAD_TOL_SMALL
+        tol = _grad_tol(float(ref.norm()), gmax, ref.ndim)
         _report(f"oracle[ViT-H-14]:   grad rel_l2={rel:.3e} |g|={float(ref.norm()):.3e} {k}")
         assert rel <= tol, (k, rel)
     # one update on both sides, then the loss on the same batch
