@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--lr-warmup-steps", type=int, default=10000, help="linear warm-up as the reference schedules it (params.py:288, scheduler.py:6-15)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--no-dense-text-line", action="store_true", help="skip the extra --dense-text timing that the default line carries")
+    ap.add_argument("--dense-text", action="store_true", help="run all context_length positions of every caption through the text tower like the reference "
+                    "does (default: packed -- only the tokens up to the pooled EOT exist; same features, loss and gradients, see model.py::_TextPack)")
     ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
     ap.add_argument("--naive-global-loss", action="store_true", help="N>1: every rank evaluates the full N x N logits (the reference's "
                     "redundant form) instead of its own rows (same loss and gradients; tests/test_dist_loss_gloo.py, test_ddp_gpu.py)")
@@ -219,6 +222,8 @@ def main():
     model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True, **extra)
     model.load_state_dict(init_state_dict(cfg, seed=0, siglip=args.siglip))
     model = model.to(dev).train()
+    if args.dense_text:
+        model.pack_text = False
     if args.grad_checkpointing:
         model.set_grad_checkpointing(True)
     B = args.local_batch
@@ -231,6 +236,15 @@ def main():
     else:
         micro = [synthetic_batch(cfg, B, seed=1234 + 1000 * j, rank=rank, device=dev) for j in range(F_ACC)]
     batch = micro[0]
+    model_ref = model
+    ctx_len = cfg["text_cfg"]["context_length"]
+    if model.pack_text:
+        kept = sum(int((m["text"].argmax(dim=-1) + 1).sum()) for m in micro)
+        text_rows_note = (f"packed: only the tokens up to the pooled EOT exist in the text tower ({kept // len(micro)} of {B * ctx_len} rows per batch, mean caption "
+                          f"{kept / (len(micro) * B):.1f} of {ctx_len} tokens; synthetic EOT position ~ U[8, {ctx_len - 1}]); features / loss / gradients "
+                          f"identical to the padded tower (tests/test_model_gpu.py::test_packed_text_tower_equals_dense_text_tower); --dense-text runs all rows")
+    else:
+        text_rows_note = f"dense: all {ctx_len} positions of every caption (as the reference)"
     pipe = None
     if args.h2d:
         # decoded pixels as a loader hands them over: uint8 [B,H,W,3] in pinned host memory (synthetic; a pool of 2 batches is cycled)
@@ -329,6 +343,24 @@ def main():
         elapsed = float(t)
     final_loss = float(loss.detach())
 
+    # the same loop with every caption padded to context_length (what the reference executes), timed right behind the packed one so
+    # that both numbers come from the same box and process; outside the K timed steps
+    dense_text = None
+    peak_bytes = torch.cuda.max_memory_allocated()
+    if model.pack_text and world == 1 and not args.no_dense_text_line:
+        model.pack_text = False
+        n_dense = max(2, min(5, args.steps))
+        step()
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        for _ in range(n_dense):
+            step()
+        torch.cuda.synchronize()
+        td = (time.perf_counter() - td) / n_dense
+        model.pack_text = True
+        dense_text = {"value": round(B * F_ACC / td, 1), "unit": "pairs/s", "ms_per_step": round(td * 1e3, 2), "steps": n_dense,
+                      "what": "same step with --dense-text (all context_length positions of every caption through the text tower)"}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = B * F_ACC * world / (elapsed / args.steps)
@@ -347,10 +379,14 @@ def main():
                        "model": args.model, "global_batch": B * F_ACC * world, "local_batch": B, "accum_freq": F_ACC, "parallelism": f"dp{world}",
                        "ddp": bool(world > 1 or args.force_ddp), "bucket_cap_mb": args.bucket_cap_mb,
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
+                       "text_tower": text_rows_note,
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
-            "step_model_tflops_per_gpu": round(value / world * flops_pair / 1e3, 1),
-            "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            # FLOPs of the model as the reference runs it (every caption padded to context_length); the packed text tower executes fewer
+            ("step_model_tflops_per_gpu" if not model_ref.pack_text else "step_dense_equivalent_model_tflops_per_gpu"): round(value / world * flops_pair / 1e3, 1),
+            "peak_hbm_gb_rank0": round(peak_bytes / 1e9, 1),
         }
+        if dense_text is not None:
+            line["dense_text_tower"] = dense_text
         if not args.no_roofline:
             s = timer.summary()
             nt, tn = s["nt"], s["tn"]

@@ -111,6 +111,14 @@ int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, int L, int H,
                     ocn_stream_t stream);
 int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int L,
                     int H, int head_dim, int causal, float scale, ocn_stream_t stream);
+/* Packed ("varlen") batches, head_dim 64.  The text tower pools x[b, argmax(text[b])] (transformer.py:941-944) under the causal
+ * mask (:1716-1722), so the tokens behind the pooled one cannot influence the feature or any gradient: the native text tower keeps
+ * only the first eot[b]+1 tokens of each sequence.  Sequence b owns rows seq_off[b] .. seq_off[b+1] of qkv / out / dout / dqkv
+ * (seq_off: B+1 ascending int32 on the device, 1 <= length <= Lmax <= 320); lse keeps the dense fp32 [B,H,Lmax] layout. */
+int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* seq_off, int B, int Lmax, int H, int causal, float scale,
+                        ocn_stream_t stream);
+int ocn_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off, int B,
+                        int Lmax, int H, int causal, float scale, ocn_stream_t stream);
 
 /* ---- image tower embedding (transformer.py:793-808) -------------------------------------------
  * patchify: image [B,3,H,W] (fp32, or bf16 when image_is_bf16) -> patches bf16 [B*gh*gw, Kpad], column order
@@ -143,9 +151,22 @@ int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* dtable, flo
 int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable, float* dpos,
                                int B, int L, int C, int vocab, ocn_stream_t stream);
 
+/* ---- packed text batches (see ocn_attn_fwd_varlen) -----------------------------------------------
+ * seq_pack_plan: eot[b] = argmax(text[b,:]); seq_off = exclusive scan of (eot+1) (B+1 entries, seq_off[B] = packed row count M);
+ *   last_row[b] = seq_off[b+1]-1 (the pooled row).  seq_pack_rows: tokens[seq_off[b]+l] = text[b,l], posidx[..] = l for l <= eot[b].
+ * token_embed_fwd_rows: x[r,:] = table[tokens[r]] + pos[posidx[r]] (fp32 [M,C]).
+ * token_embed_bwd_sorted_varlen: ocn_token_embed_bwd_sorted over the M packed rows (sorted_tokens / order index packed rows). */
+int ocn_seq_pack_plan(const int64_t* text, int32_t* eot, int32_t* seq_off, int32_t* last_row, int B, int L, ocn_stream_t stream);
+int ocn_seq_pack_rows(const int64_t* text, const int32_t* seq_off, int64_t* tokens, int32_t* posidx, int B, int L, ocn_stream_t stream);
+int ocn_token_embed_fwd_rows(const int64_t* tokens, const int32_t* posidx, const float* table, const float* pos, float* x, long M, int C,
+                             int vocab, ocn_stream_t stream);
+int ocn_token_embed_bwd_sorted_varlen(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable,
+                                      float* dpos, const int32_t* seq_off, int B, int L, long M, int C, int vocab, ocn_stream_t stream);
+
 /* ---- pooling (transformer.py:786-787 'tok'; :941-944 'argmax') ---------------------------------
  * argmax_rows: idx[b] = first index of max(text[b,:]) (torch.argmax semantics)
- * gather_rows: out[b,:] = x[(b*L + idx[b]),:] (idx NULL -> token 0);  scatter_rows: dx (pre-zeroed)[b*L+idx[b],:] = d[b,:] */
+ * gather_rows: out[b,:] = x[(b*L + idx[b]),:] (idx NULL -> token 0);  scatter_rows: dx (pre-zeroed)[b*L+idx[b],:] = d[b,:]
+ *   (L = 0: idx holds absolute row numbers -- the packed text tower's last_row) */
 int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, ocn_stream_t stream);
 int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream);
 int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,

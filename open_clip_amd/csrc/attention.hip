@@ -27,7 +27,21 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-// stage rows [0, LP) (clamped to L-1) of one head's 64-wide column block into LDS; all waves cooperate
+// Rows of sequence b inside the [rows, 3C] qkv matrix.  Dense batches: Lmax rows each.  Packed ("varlen") batches: only the first
+// seq_off[b+1] - seq_off[b] tokens of a sequence exist (the text tower drops everything behind the pooled EOT token: under the
+// causal mask those positions cannot influence it -- reference transformer.py:941-944 pools x[argmax], :1716-1722 is the mask).
+struct SeqSpan {
+    size_t row0;
+    int len;
+};
+OCN_DEV SeqSpan seq_span(const int32_t* __restrict__ seq_off, int b, int Lmax) {
+    if (!seq_off) return {(size_t)b * Lmax, Lmax};
+    const int o = seq_off[b];
+    return {(size_t)o, seq_off[b + 1] - o};
+}
+
+// stage rows [0, LP) (clamped to L-1) of one head's 64-wide column block into LDS; all waves cooperate.  LP = the sequence's own
+// length rounded up to 32: a packed (varlen) batch never touches the 32-row blocks behind it.
 // NTL: non-temporal policy for the head's rows (read by this workgroup only) -- measured no faster than the default policy
 // (profiles/r01_attn_cache_policy.txt), kept as developer knob 9 = 2 of the forward
 template <bool NTL = false>
@@ -103,7 +117,8 @@ OCN_DEV void flush_tile(const char* img, int row0, int lane, bf16* base, size_t 
 // ------------------------------------------------------------------------------------------------
 template <int MAXT, bool NTL>
 __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                         float* __restrict__ lse, int L, int H, int causal, float scale) {
+                                                         float* __restrict__ lse, const int32_t* __restrict__ seq_off, int Lmax, int H,
+                                                         int causal, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,13 +127,15 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
     const int b = blockIdx.x / H, hd = blockIdx.x % H;
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
-    const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
+    const SeqSpan sp = seq_span(seq_off, b, Lmax);  // dense: rows b*Lmax .. +Lmax; packed: rows seq_off[b] .. seq_off[b+1]
+    const int L = sp.len, nb = (L + 31) >> 5, LPe = nb * 32;
+    const bf16* qbase = qkv + sp.row0 * rs + hd * 64;
     char* sQ = smem;
     char* sK = smem + LP * 128;
     char* sV = smem + 2 * LP * 128;
-    stage_head<NTL>(qbase, rs, L, LP, sQ, wave, nwaves, lane);
-    stage_head<NTL>(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
-    stage_head<NTL>(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
+    stage_head<NTL>(qbase, rs, L, LPe, sQ, wave, nwaves, lane);
+    stage_head<NTL>(qbase + C, rs, L, LPe, sK, wave, nwaves, lane);
+    stage_head<NTL>(qbase + 2 * C, rs, L, LPe, sV, wave, nwaves, lane);
 
     const int qb = wave;
     const int lr = lane & 31, lh = lane >> 5;
@@ -126,6 +143,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (qb >= nb) return;  // a query block behind the end of a short packed sequence (no barrier follows)
     bf16x8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = frag_rows(sQ, query, s, lane);  // rows >= L are copies of row L-1 (stage_head clamps)
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
     const float sc = scale * LOG2E;
     float m = -1e30f, l = 0.f;
     f32x16 o0 = zero16(), o1 = zero16();
-    const int nkb = causal ? qb + 1 : nwaves;
+    const int nkb = causal ? qb + 1 : nb;
     for (int kb = 0; kb < nkb; ++kb) {
         f32x16 st = zero16();
 #pragma unroll
@@ -173,8 +191,8 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
     const float inv = 1.0f / l;
     // O goes out through this wave's own (already consumed) rows of the Q image
     stage_tile(sQ, qb * 32, lane, o0, o1, inv);
-    flush_tile(sQ, qb * 32, lane, out + (size_t)b * L * C + hd * 64, (size_t)C, L);
-    if (query < L && lh == 0) lse[((size_t)b * H + hd) * L + query] = (m + log2f(l)) * LN2;
+    flush_tile(sQ, qb * 32, lane, out + sp.row0 * C + hd * 64, (size_t)C, L);
+    if (query < L && lh == 0) lse[((size_t)b * H + hd) * Lmax + query] = (m + log2f(l)) * LN2;  // lse stays [B, H, Lmax]
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -185,7 +203,8 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
 template <int MAXT, int WPE>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                         bf16* __restrict__ dqkv, int L, int H, int causal, float scale, int ablate) {
+                                                         bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, int causal,
+                                                         float scale, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -194,9 +213,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const int b = blockIdx.x / H, hd = blockIdx.x % H;
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
-    const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
-    const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
-    const bf16* obase = out + (size_t)b * L * C + hd * 64;
+    const SeqSpan sp = seq_span(seq_off, b, Lmax);
+    const int L = sp.len, nb = (L + 31) >> 5, LPe = nb * 32;
+    const bool active = wave < nb;  // waves behind the end of a short packed sequence only take part in the barriers
+    const bf16* qbase = qkv + sp.row0 * rs + hd * 64;
+    const bf16* dobase = dout + sp.row0 * C + hd * 64;
+    const bf16* obase = out + sp.row0 * C + hd * 64;
     // Three images instead of four: the arithmetic of this kernel is latency-bound and its rate scales with the number of
     // resident workgroups (measured: profiles/r01_attn_bwd_occupancy.txt), and LDS is what caps that number.  Pass 1 holds K,
     // V and dO (dQ needs all keys; the wave's own Q and O rows come straight from global memory into fragments); before pass 2
@@ -211,9 +233,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const int lr = lane & 31, lh = lane >> 5;
     const float sc = scale * LOG2E;
     if (!(ablate & 1)) {
-        stage_head(qbase + C, rs, L, LP, sA, wave, nwaves, lane);
-        stage_head(qbase + 2 * C, rs, L, LP, sB, wave, nwaves, lane);
-        stage_head(dobase, (size_t)C, L, LP, sC, wave, nwaves, lane);
+        stage_head(qbase + C, rs, L, LPe, sA, wave, nwaves, lane);
+        stage_head(qbase + 2 * C, rs, L, LPe, sB, wave, nwaves, lane);
+        stage_head(dobase, (size_t)C, L, LPe, sC, wave, nwaves, lane);
     }
 
     // ---- phase A: dQ for query block `wave` (lane <-> query, registers <-> keys) ----
@@ -231,11 +253,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 qf[s] = *(const bf16x8*)(qbase + (size_t)qrow * rs + (s * 2 + lh) * 8);
                 of[s] = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
             }
-            lse_q = lse[((size_t)b * H + hd) * L + qrow] * LOG2E;  // exp2 units
+            lse_q = lse[((size_t)b * H + hd) * Lmax + qrow] * LOG2E;  // exp2 units
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                qf[s] = frag_rows(sA, query, s, lane);
+                qf[s] = frag_rows(sA, active ? query : lr, s, lane);
                 of[s] = qf[s];
             }
         }
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         // delta[q] = sum_d dO[q,d] * O[q,d] (each half-wave holds 32 of the 64 d's)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            dof[s] = frag_rows(sC, query, s, lane);
+            dof[s] = frag_rows(sC, active ? query : lr, s, lane);
 #pragma unroll
             for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[s][e]);
         }
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             sLse[query] = lse_q;
             sDelta[query] = delta_q;
         }
-        const int nkb = (ablate & 2) ? 0 : (causal ? qb + 1 : nwaves);
+        const int nkb = ((ablate & 2) || !active) ? 0 : (causal ? qb + 1 : nb);
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
@@ -284,21 +306,21 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            kf[s] = frag_rows(sA, key, s, lane);
-            vf[s] = frag_rows(sB, key, s, lane);
+            kf[s] = frag_rows(sA, active ? key : lr, s, lane);
+            vf[s] = frag_rows(sB, active ? key : lr, s, lane);
         }
         // every wave has finished phase A and holds its K / V fragments: Q is staged over K while dQ leaves through the V
         // image (keeping dQ in registers across phase B would cost occupancy)
         __syncthreads();
-        bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
-        if (!(ablate & 1)) stage_head(qbase, rs, L, LP, sA, wave, nwaves, lane);
+        bf16* dbase = dqkv + sp.row0 * rs + hd * 64;
+        if (!(ablate & 1)) stage_head(qbase, rs, L, LPe, sA, wave, nwaves, lane);
         stage_tile(sB, wave * 32, lane, dq0, dq1, 1.0f);
         if (!(ablate & 4)) flush_tile(sB, wave * 32, lane, dbase, rs, L);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-        const int qb0 = (ablate & 2) ? nwaves : (causal ? kb : 0);
-        for (int qb = qb0; qb < nwaves; ++qb) {
+        const int qb0 = ((ablate & 2) || !active) ? nb : (causal ? kb : 0);
+        for (int qb = qb0; qb < nb; ++qb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -342,7 +364,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 template <int MAXT, int WPE>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_causal_kernel(
     const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout, const float* __restrict__ lse,
-    bf16* __restrict__ dqkv, int L, int H, float scale) {
+    bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -351,9 +373,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     const int b = blockIdx.x / H, hd = blockIdx.x % H;
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
-    const bf16* qbase = qkv + (size_t)b * L * rs + hd * 64;
-    const bf16* dobase = dout + (size_t)b * L * C + hd * 64;
-    const bf16* obase = out + (size_t)b * L * C + hd * 64;
+    const SeqSpan sp = seq_span(seq_off, b, Lmax);
+    const int L = sp.len, nb = (L + 31) >> 5, LPe = nb * 32;
+    const bf16* qbase = qkv + sp.row0 * rs + hd * 64;
+    const bf16* dobase = dout + sp.row0 * C + hd * 64;
+    const bf16* obase = out + sp.row0 * C + hd * 64;
     char* sQ = smem;
     char* sK = smem + LP * 128;
     char* sV = smem + 2 * LP * 128;
@@ -363,27 +387,28 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     float* sDelta = sLse + LP;
     const int lr = lane & 31, lh = lane >> 5;
     const float sc = scale * LOG2E;
-    stage_head(qbase, rs, L, LP, sQ, wave, nwaves, lane);
-    stage_head(qbase + C, rs, L, LP, sK, wave, nwaves, lane);
-    stage_head(qbase + 2 * C, rs, L, LP, sV, wave, nwaves, lane);
-    stage_head(dobase, (size_t)C, L, LP, sdO, wave, nwaves, lane);
+    stage_head(qbase, rs, L, LPe, sQ, wave, nwaves, lane);
+    stage_head(qbase + C, rs, L, LPe, sK, wave, nwaves, lane);
+    stage_head(qbase + 2 * C, rs, L, LPe, sV, wave, nwaves, lane);
+    stage_head(dobase, (size_t)C, L, LPe, sdO, wave, nwaves, lane);
     const int qb = wave, query = qb * 32 + lr;
     const int qrow = query < L ? query : L - 1;
     bf16x8 of[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) of[s] = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
-    const float lse_q = lse[((size_t)b * H + hd) * L + qrow] * LOG2E;
+    const float lse_q = lse[((size_t)b * H + hd) * Lmax + qrow] * LOG2E;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    bf16* dbase = dqkv + (size_t)b * L * rs + hd * 64;
+    bf16* dbase = dqkv + sp.row0 * rs + hd * 64;
+    const bool active = wave < nb;  // waves behind the end of a short packed sequence only take part in the barriers
 
     // every wave first publishes lse / delta of its query block (phase B of OTHER waves reads them) ...
     bf16x8 qf[4], dof[4];
     float delta_q = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        qf[s] = frag_rows(sQ, query, s, lane);
-        dof[s] = frag_rows(sdO, query, s, lane);
+        qf[s] = frag_rows(sQ, active ? query : lr, s, lane);
+        dof[s] = frag_rows(sdO, active ? query : lr, s, lane);
 #pragma unroll
         for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[s][e]);
     }
@@ -393,6 +418,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         sDelta[query] = delta_q;
     }
     __syncthreads();
+    if (!active) return;  // no barrier follows
 
     // ---- phase A: dQ for query block `wave` (keys 0 .. query block) ----
     {
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             vf[s] = frag_rows(sV, key, s, lane);
         }
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-        for (int q2 = kb; q2 < nwaves; ++q2) {
+        for (int q2 = kb; q2 < nb; ++q2) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -473,30 +499,31 @@ int check_attn(const char* name, int B, int L, int H) {
 
 }  // namespace
 
-extern "C" int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int causal, float scale,
-                            ocn_stream_t stream) {
+namespace {
+int attn_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* seq_off, int B, int L, int H, int causal, float scale,
+                  ocn_stream_t stream) {
     OCN_CHECK_ARG(qkv && out && lse, "ocn_attn_fwd: null operand");
     if (int e = check_attn("ocn_attn_fwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
     const int lds = 3 * nw * 32 * 128;
     const bool ntl = g_ocn_tuning[9] == 2;
     if (nw <= 4) {
-        if (ntl) hipLaunchKernelGGL((attn_fwd_kernel<256, true>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, L, H, causal, scale);
-        else hipLaunchKernelGGL((attn_fwd_kernel<256, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, L, H, causal, scale);
+        if (ntl) hipLaunchKernelGGL((attn_fwd_kernel<256, true>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale);
+        else hipLaunchKernelGGL((attn_fwd_kernel<256, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<640, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<640, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, L, H, causal, scale);
+        hipLaunchKernelGGL((attn_fwd_kernel<640, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale);
     }
     OCN_CHECK_LAUNCH("ocn_attn_fwd");
     return OCN_OK;
 }
 
-extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L,
-                            int H, int causal, float scale, ocn_stream_t stream) {
+int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off, int B, int L,
+                  int H, int causal, float scale, ocn_stream_t stream) {
     OCN_CHECK_ARG(qkv && out && dout && lse && dqkv, "ocn_attn_bwd: null operand");
     if (int e = check_attn("ocn_attn_bwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
@@ -511,7 +538,7 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
             cattr_set = true;
         }
         hipLaunchKernelGGL((attn_bwd_causal_kernel<256, 2>), dim3(B * H), dim3(nw * 64), lds5, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, scale);
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, scale);
         OCN_CHECK_LAUNCH("ocn_attn_bwd");
         return OCN_OK;
     }
@@ -523,7 +550,7 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
             attr_set = true;
         }
         hipLaunchKernelGGL((attn_bwd_kernel<256, 3>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1]);
     } else if (nw <= 4) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -531,7 +558,7 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
             attr_set = true;
         }
         hipLaunchKernelGGL((attn_bwd_kernel<256, 2>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1]);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -539,10 +566,34 @@ extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, 
             attr_set = true;
         }
         hipLaunchKernelGGL((attn_bwd_kernel<640, 1>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, L, H, causal, scale, g_ocn_tuning[1]);
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1]);
     }
     OCN_CHECK_LAUNCH("ocn_attn_bwd");
     return OCN_OK;
+}
+}  // namespace
+
+extern "C" int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int causal, float scale, ocn_stream_t stream) {
+    return attn_fwd_impl(qkv, out, lse, nullptr, B, L, H, causal, scale, stream);
+}
+
+extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L, int H,
+                            int causal, float scale, ocn_stream_t stream) {
+    return attn_bwd_impl(qkv, out, dout, lse, dqkv, nullptr, B, L, H, causal, scale, stream);
+}
+
+// Packed ("varlen") batches, head_dim 64: sequence b owns rows seq_off[b] .. seq_off[b+1] of qkv / out / dout / dqkv
+// (1 <= length <= Lmax, seq_off = B + 1 ascending int32 on the device); lse keeps the dense [B, H, Lmax] layout.
+extern "C" int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* seq_off, int B, int Lmax, int H, int causal,
+                                   float scale, ocn_stream_t stream) {
+    OCN_CHECK_ARG(seq_off, "ocn_attn_fwd_varlen: null seq_off");
+    return attn_fwd_impl(qkv, out, lse, seq_off, B, Lmax, H, causal, scale, stream);
+}
+
+extern "C" int ocn_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off,
+                                   int B, int Lmax, int H, int causal, float scale, ocn_stream_t stream) {
+    OCN_CHECK_ARG(seq_off, "ocn_attn_bwd_varlen: null seq_off");
+    return attn_bwd_impl(qkv, out, dout, lse, dqkv, seq_off, B, Lmax, H, causal, scale, stream);
 }
 
 // ---- explicit head_dim: dispatch between the specialised (head_dim 64, head resident) and the generic kernels ---------------

@@ -247,6 +247,93 @@ __global__ void pos_grad_kernel(const T* __restrict__ dx, float* __restrict__ dp
     for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dpos + (size_t)l * C + c + e, acc[e]);
 }
 
+// ---- packed ("varlen") text batches ----------------------------------------------------------------------------------------------
+// The text tower pools x[b, argmax(text[b])] (transformer.py:941-944) under a causal mask (:1716-1722): tokens behind the pooled
+// one cannot influence the feature, so only the first eot[b] + 1 tokens of each sequence are kept.  seq_off = exclusive scan of those
+// lengths (B + 1 entries), last_row[b] = seq_off[b+1] - 1 = the pooled row.  One workgroup (B is a few thousand).
+__global__ __launch_bounds__(1024) void seq_plan_kernel(const int32_t* __restrict__ eot, int32_t* __restrict__ seq_off,
+                                                        int32_t* __restrict__ last_row, int B) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) {
+        carry_s = 0;
+        seq_off[0] = 0;
+    }
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int i = base + tid;
+        int v = i < B ? eot[i] + 1 : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o, 64);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int pre = carry_s;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        v += pre;  // inclusive prefix over the whole batch
+        if (i < B) {
+            seq_off[i + 1] = v;
+            last_row[i] = v - 1;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = v;
+        __syncthreads();
+    }
+}
+
+// tokens[r] / posidx[r] of packed row r = seq_off[b] + l  (l <= eot[b])
+__global__ void seq_pack_rows_kernel(const int64_t* __restrict__ text, const int32_t* __restrict__ seq_off, int64_t* __restrict__ tokens,
+                                     int32_t* __restrict__ posidx, int B, int L) {
+    const long total = (long)B * L;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / L), l = (int)(i % L);
+        const int o = seq_off[b];
+        if (l < seq_off[b + 1] - o) {
+            tokens[o + l] = text[i];
+            posidx[o + l] = l;
+        }
+    }
+}
+
+__global__ void token_embed_fwd_rows_kernel(const int64_t* __restrict__ tokens, const int32_t* __restrict__ posidx,
+                                            const float* __restrict__ table, const float* __restrict__ pos, float* __restrict__ x, long M,
+                                            int C, int vocab) {
+    const int c4n = C / 4;
+    const long total = M * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long r = idx / c4n;
+        long tok = tokens[r];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        *(f32x4*)(x + (size_t)r * C + c) = *(const f32x4*)(table + (size_t)tok * C + c) + *(const f32x4*)(pos + (size_t)posidx[r] * C + c);
+    }
+}
+
+// dpos[l, :] += sum over the sequences that HAVE a position l of dx[seq_off[b] + l, :]
+template <typename T>
+__global__ void pos_grad_varlen_kernel(const T* __restrict__ dx, float* __restrict__ dpos, const int32_t* __restrict__ seq_off, int B, int L,
+                                       int C, int bchunk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, c4n = C / 4;
+    if (idx >= L * c4n) return;
+    const int l = idx / c4n, c = (idx % c4n) * 4;
+    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (int b = b0; b < b1; ++b) {
+        const int o = seq_off[b];
+        if (l < seq_off[b + 1] - o) {
+            acc += load4f<T>(dx + ((size_t)o + l) * C + c);
+            any = true;
+        }
+    }
+    if (!any) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dpos + (size_t)l * C + c + e, acc[e]);
+}
+
 // ---- pooling ---------------------------------------------------------------------------------------
 __global__ void argmax_rows_kernel(const int64_t* __restrict__ text, int32_t* __restrict__ idx, int B, int L) {
     const int lane = threadIdx.x & 63;
@@ -450,6 +537,51 @@ extern "C" int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const in
     return OCN_OK;
 }
 
+extern "C" int ocn_seq_pack_plan(const int64_t* text, int32_t* eot, int32_t* seq_off, int32_t* last_row, int B, int L, ocn_stream_t stream) {
+    OCN_CHECK_ARG(text && eot && seq_off && last_row && B > 0 && L > 0, "ocn_seq_pack_plan: bad arguments");
+    OCN_CHECK_ARG((long)B * L < 0x7fffffffL, "ocn_seq_pack_plan: B*L = %ld rows exceed int32 offsets", (long)B * L);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(ocn_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, text, eot, B, L);
+    hipLaunchKernelGGL(seq_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, eot, seq_off, last_row, B);
+    OCN_CHECK_LAUNCH("ocn_seq_pack_plan");
+    return OCN_OK;
+}
+
+extern "C" int ocn_seq_pack_rows(const int64_t* text, const int32_t* seq_off, int64_t* tokens, int32_t* posidx, int B, int L,
+                                 ocn_stream_t stream) {
+    OCN_CHECK_ARG(text && seq_off && tokens && posidx && B > 0 && L > 0, "ocn_seq_pack_rows: bad arguments");
+    hipLaunchKernelGGL(seq_pack_rows_kernel, dim3(grid_for((long)B * L, 256)), dim3(256), 0, (hipStream_t)stream, text, seq_off, tokens, posidx, B, L);
+    OCN_CHECK_LAUNCH("ocn_seq_pack_rows");
+    return OCN_OK;
+}
+
+extern "C" int ocn_token_embed_fwd_rows(const int64_t* tokens, const int32_t* posidx, const float* table, const float* pos, float* x, long M,
+                                        int C, int vocab, ocn_stream_t stream) {
+    OCN_CHECK_ARG(tokens && posidx && table && pos && x, "ocn_token_embed_fwd_rows: null operand");
+    OCN_CHECK_ARG(M > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_fwd_rows: bad shape");
+    hipLaunchKernelGGL(token_embed_fwd_rows_kernel, dim3(grid_for(M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, tokens, posidx, table, pos, x, M, C, vocab);
+    OCN_CHECK_LAUNCH("ocn_token_embed_fwd_rows");
+    return OCN_OK;
+}
+
+extern "C" int ocn_token_embed_bwd_sorted_varlen(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable,
+                                                 float* dpos, const int32_t* seq_off, int B, int L, long M, int C, int vocab, ocn_stream_t stream) {
+    OCN_CHECK_ARG(sorted_tokens && order && dx && dtable && dpos && seq_off, "ocn_token_embed_bwd_sorted_varlen: null operand");
+    OCN_CHECK_ARG(B > 0 && L > 0 && M > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_bwd_sorted_varlen: bad shape");
+    OCN_CHECK_ARG(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dtable & 15) == 0, "ocn_token_embed_bwd_sorted_varlen: operands must be 16-byte aligned");
+    const int CH = 64, bchunk = 128;
+    const dim3 g1((unsigned)ocn_cdiv(M, CH)), g2(ocn_cdiv((long)L * (C / 4), 256), ocn_cdiv(B, bchunk));
+    hipStream_t st = (hipStream_t)stream;
+    if (dx_is_bf16) {
+        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<bf16>, g1, dim3(128), 0, st, sorted_tokens, order, (const bf16*)dx, dtable, M, C, vocab, CH);
+        hipLaunchKernelGGL(pos_grad_varlen_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dx, dpos, seq_off, B, L, C, bchunk);
+    } else {
+        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<float>, g1, dim3(128), 0, st, sorted_tokens, order, (const float*)dx, dtable, M, C, vocab, CH);
+        hipLaunchKernelGGL(pos_grad_varlen_kernel<float>, g2, dim3(256), 0, st, (const float*)dx, dpos, seq_off, B, L, C, bchunk);
+    }
+    OCN_CHECK_LAUNCH("ocn_token_embed_bwd_sorted_varlen");
+    return OCN_OK;
+}
+
 extern "C" int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, ocn_stream_t stream) {
     OCN_CHECK_ARG(text && idx && B > 0 && L > 0, "ocn_argmax_rows: bad arguments");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(ocn_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, text, idx, B, L);
@@ -458,7 +590,7 @@ extern "C" int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, 
 }
 
 extern "C" int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream) {
-    OCN_CHECK_ARG(x && out && B > 0 && L > 0 && C % 4 == 0, "ocn_gather_rows: bad arguments");
+    OCN_CHECK_ARG(x && out && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_gather_rows: bad arguments");
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, L, C);
     OCN_CHECK_LAUNCH("ocn_gather_rows");
     return OCN_OK;
@@ -466,7 +598,7 @@ extern "C" int ocn_gather_rows(const float* x, const int32_t* idx, float* out, i
 
 extern "C" int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
                                 ocn_stream_t stream) {
-    OCN_CHECK_ARG(d && (dx || dx_bf16) && B > 0 && L > 0 && C % 4 == 0, "ocn_scatter_rows: bad arguments");
+    OCN_CHECK_ARG(d && (dx || dx_bf16) && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_scatter_rows: bad arguments");
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, d, idx, dx, (bf16*)dx_bf16, B, L, C);
     OCN_CHECK_LAUNCH("ocn_scatter_rows");
     return OCN_OK;

@@ -13,6 +13,7 @@ block by block while the backward is still running, and block-granular recompute
 is a flag of the same Function.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -174,13 +175,13 @@ class _Paired:
 # ------------------------------------------------------------------------------------------------------
 # residual block (transformer.py:319-330)
 # ------------------------------------------------------------------------------------------------------
-def _block_forward(x, p, cache, B, L, heads, causal):
+def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
     (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
     M, C = x.shape
     h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
     qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
     hd = C // heads
-    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd)
+    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd, seq_off)
     xmid = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, cache.get(wo, "n"), ops.empty((M, C), F32, x), bias=bo, resid=x)
     h2, _, mean2, rstd2 = ops.layernorm_fwd(xmid, ln2w, ln2b)
     Fd = wfc.shape[0]
@@ -192,10 +193,11 @@ def _block_forward(x, p, cache, B, L, heads, causal):
 
 class _BlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, cache, B, L, heads, causal, recompute):
+    def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, cache, B, L, heads, causal, recompute,
+                seq_off=None):
         p = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj)
-        y, saved = _block_forward(x, p, cache, B, L, heads, causal)
-        ctx.meta = (cache, B, L, heads, causal, recompute)
+        y, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off)
+        ctx.meta = (cache, B, L, heads, causal, recompute, seq_off)
         if recompute:  # block-granular activation recompute (transformer.py:579-581): keep only the block input
             ctx.save_for_backward(x, *p)
         else:
@@ -204,12 +206,12 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        cache, B, L, heads, causal, recompute = ctx.meta
+        cache, B, L, heads, causal, recompute, seq_off = ctx.meta
         t = ctx.saved_tensors
         x, p = t[0], t[1:13]
         (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
         if recompute:
-            _, saved = _block_forward(x, p, cache, B, L, heads, causal)
+            _, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off)
         else:
             saved = t[13:]
         (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g) = saved
@@ -252,7 +254,7 @@ class _BlockFn(torch.autograd.Function):
         with _Paired(dev, _PAIR_MODE in ("all", "attn")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
-            dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads)
+            dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev, _PAIR_MODE in ("all", "ln")) as side:
             if need_w:
@@ -269,7 +271,7 @@ class _BlockFn(torch.autograd.Function):
             _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
-        return (dx, *grads, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -323,8 +325,12 @@ class _VisionEmbedFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 class _TextEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, text, table, pos):
-        x = ops.token_embed_fwd(text.contiguous(), table, pos)
+    def forward(ctx, text, table, pos, pack=None):
+        if pack is None:
+            x = ops.token_embed_fwd(text.contiguous(), table, pos)
+        else:
+            x = ops.token_embed_fwd_rows(pack.tokens, pack.posidx, table, pos)
+        ctx.pack = pack
         ctx.save_for_backward(text, table, pos)
         return x
 
@@ -333,8 +339,39 @@ class _TextEmbedFn(torch.autograd.Function):
         text, table, pos = ctx.saved_tensors
         dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
         dxv = _take_twin(dx) if _is_placeholder(dx) else dx.contiguous()  # bf16 when the blocks hand their gradient over in bf16
-        ops.token_embed_bwd_sorted(text.contiguous(), dxv, dtable, dpos)
-        return None, dtable, dpos
+        if ctx.pack is None:
+            ops.token_embed_bwd_sorted(text.contiguous(), dxv, dtable, dpos)
+        else:
+            B, L = text.shape
+            ops.token_embed_bwd_sorted_varlen(ctx.pack.tokens, ctx.pack.seq_off, B, L, dxv, dtable, dpos)
+        return None, dtable, dpos, None
+
+
+class _TextPack:
+    """Packed layout of one text batch (``ocn_seq_pack_plan``): only the first ``argmax(text[b]) + 1`` tokens of each sequence exist
+    in the text tower.  The reference pools ``x[b, text[b].argmax()]`` (transformer.py:941-944) behind a causal mask (:1716-1722),
+    so the positions after the pooled one influence neither the feature nor any gradient -- dropping them changes no result and
+    removes their share of every GEMM / LayerNorm / attention launch of the tower (tokenizer output is ~60 % padding on LAION-like
+    captions).  ``plan()`` enqueues the two planning kernels and the 4-byte device -> host copy of the packed row count; ``finish()``
+    waits for that copy (the only host synchronisation of the step; it is issued BEFORE the image tower so that it never drains
+    the queue) and builds the packed token / position lists."""
+
+    def __init__(self, text):
+        self.text = text = text.contiguous()
+        self.B, self.L = text.shape
+        self.eot, self.seq_off, self.last_row = ops.seq_pack_plan(text)
+        self._m_host = torch.empty(1, dtype=torch.int32).pin_memory()
+        self._m_host.copy_(self.seq_off[self.B:], non_blocking=True)
+        self._ready = torch.cuda.Event()
+        self._ready.record()
+        self.M = None
+
+    def finish(self):
+        if self.M is None:
+            self._ready.synchronize()
+            self.M = int(self._m_host[0])
+            self.tokens, self.posidx = ops.seq_pack_rows(self.text, self.seq_off, self.M)
+        return self
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -439,8 +476,8 @@ class ResidualAttentionBlock(nn.Module):  # transformer.py:274-330
     def get_weight_dtype(self):
         return self.mlp.c_fc.weight.dtype
 
-    def forward(self, x, cache, B, L, causal, recompute=False):
-        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute)
+    def forward(self, x, cache, B, L, causal, recompute=False, seq_off=None):
+        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute, seq_off)
 
 
 class Transformer(nn.Module):  # transformer.py:476-585
@@ -456,10 +493,10 @@ class Transformer(nn.Module):  # transformer.py:476-585
     def set_grad_checkpointing(self, enable=True, impl="inline"):
         self.grad_checkpointing = enable
 
-    def forward(self, x, cache, B, L, causal):
+    def forward(self, x, cache, B, L, causal, seq_off=None):
         rc = self.grad_checkpointing and torch.is_grad_enabled()
         for r in self.resblocks:
-            x = r(x, cache, B, L, causal, rc)
+            x = r(x, cache, B, L, causal, rc, seq_off)
         return x
 
 
@@ -618,6 +655,9 @@ class NativeCLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * init_logit_scale)
         self.logit_bias = nn.Parameter(torch.ones([]) * init_logit_bias) if init_logit_bias is not None else None
         self._cache = _WeightCache()
+        # packed text tower (see _TextPack): on by default where the varlen attention kernels apply (head_dim 64, L <= 320);
+        # ``model.pack_text = False`` (or OCN_TEXT_PACK=0) runs every one of the context_length positions like the reference does
+        self.pack_text = (os.environ.get("OCN_TEXT_PACK", "1") != "0" and t["width"] // t["heads"] == 64 and self.context_length <= 320)
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
         # manual re-initialisation) do not move the counter, so every load_state_dict drops them
@@ -677,10 +717,16 @@ class NativeCLIP(nn.Module):
     def encode_image(self, image, normalize: bool = False):
         return self.visual(image, normalize)
 
-    def encode_text(self, text, normalize: bool = False):
+    def encode_text(self, text, normalize: bool = False, _pack=None):
         B, L = text.shape
         if L != self.context_length:
             raise RuntimeError(f"text length {L} != context_length {self.context_length}")
+        if self.pack_text:
+            pack = (_pack if _pack is not None else _TextPack(text)).finish()
+            x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)
+            x = self.transformer(x, self._cache, B, L, True, pack.seq_off)
+            # L = 0: last_row holds absolute rows of the packed matrix
+            return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, pack.last_row, self._cache, B, 0, normalize)
         x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
         x = self.transformer(x, self._cache, B, L, True)
         idx = ops.argmax_rows(text.contiguous())
@@ -694,8 +740,10 @@ class NativeCLIP(nn.Module):
         return li, li.T
 
     def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):
+        # the packed text layout is planned first: its 4-byte read-back then completes while the image tower is being enqueued
+        pack = _TextPack(text) if (text is not None and self.pack_text) else None
         image_features = self.encode_image(image, normalize=True) if image is not None else None
-        text_features = self.encode_text(text, normalize=True) if text is not None else None
+        text_features = self.encode_text(text, normalize=True, _pack=pack) if text is not None else None
         if self.output_dict:
             out = {"image_features": image_features, "text_features": text_features, "logit_scale": self.logit_scale.exp()}
             if self.logit_bias is not None:

@@ -131,8 +131,17 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_b
 
 
 # ---- attention -------------------------------------------------------------------------------------------
-def attn_fwd(qkv, B, L, H, causal, scale, head_dim=64):
+def attn_fwd(qkv, B, L, H, causal, scale, head_dim=64, seq_off=None):
+    """``seq_off`` (int32 [B+1], device): packed batch -- sequence b owns rows seq_off[b]..seq_off[b+1] of qkv (head_dim 64 only)"""
     C = H * head_dim
+    if seq_off is not None:
+        if head_dim != 64 or qkv.shape[1] != 3 * C or seq_off.numel() != B + 1:
+            raise RuntimeError(f"attn_fwd(varlen): needs head_dim 64 and seq_off of B+1 entries (qkv {tuple(qkv.shape)}, head_dim {head_dim})")
+        out = empty((qkv.shape[0], C), BF16, qkv)
+        lse = empty((B * H * L,), F32, qkv)
+        _lib.call("ocn_attn_fwd_varlen", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), _chk(seq_off, torch.int32, "seq_off"),
+                  B, L, H, int(causal), float(scale), _stream())
+        return out, lse
     if qkv.shape != (B * L, 3 * C):
         raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(B * L, 3 * C)} (H={H}, head_dim={head_dim})")
     out = empty((B * L, C), BF16, qkv)
@@ -142,8 +151,12 @@ def attn_fwd(qkv, B, L, H, causal, scale, head_dim=64):
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale, head_dim=64):
+def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale, head_dim=64, seq_off=None):
     dqkv = empty(qkv.shape, BF16, qkv)
+    if seq_off is not None:
+        _lib.call("ocn_attn_bwd_varlen", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
+                  _chk(dqkv, BF16, "dqkv"), _chk(seq_off, torch.int32, "seq_off"), B, L, H, int(causal), float(scale), _stream())
+        return dqkv
     delta = empty((B * H * L,), F32, qkv)  # workspace of the generic path (exchanged between its two launches)
     _lib.call("ocn_attn_bwd_hd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
               _chk(dqkv, BF16, "dqkv"), _chk(delta, F32, "delta"), B, L, H, head_dim, int(causal), float(scale), _stream())
@@ -215,6 +228,43 @@ def token_embed_bwd_sorted(text, dx, dtable, dpos):
     is16 = dx.dtype == BF16
     _lib.call("ocn_token_embed_bwd_sorted", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"),
               _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
+
+
+def seq_pack_plan(text):
+    """(eot [B], seq_off [B+1], last_row [B]) int32 on the device: the packed layout of a text batch (ocn_seq_pack_plan)"""
+    B, L = text.shape
+    eot, seq_off, last_row = empty((B,), torch.int32, text), empty((B + 1,), torch.int32, text), empty((B,), torch.int32, text)
+    _lib.call("ocn_seq_pack_plan", _chk(text, torch.int64, "text"), _chk(eot, torch.int32, "eot"), _chk(seq_off, torch.int32, "seq_off"),
+              _chk(last_row, torch.int32, "last_row"), B, L, _stream())
+    return eot, seq_off, last_row
+
+
+def seq_pack_rows(text, seq_off, M):
+    B, L = text.shape
+    tokens, posidx = empty((M,), torch.int64, text), empty((M,), torch.int32, text)
+    _lib.call("ocn_seq_pack_rows", _chk(text, torch.int64, "text"), _chk(seq_off, torch.int32, "seq_off"), _chk(tokens, torch.int64, "tokens"),
+              _chk(posidx, torch.int32, "posidx"), B, L, _stream())
+    return tokens, posidx
+
+
+def token_embed_fwd_rows(tokens, posidx, table, pos):
+    M = tokens.numel()
+    vocab, C = table.shape
+    x = empty((M, C), F32, table)
+    _lib.call("ocn_token_embed_fwd_rows", _chk(tokens, torch.int64, "tokens"), _chk(posidx, torch.int32, "posidx"), _chk(table, F32, "table"),
+              _chk(pos, F32, "pos"), _chk(x, F32, "x"), M, C, vocab, _stream())
+    return x
+
+
+def token_embed_bwd_sorted_varlen(tokens, seq_off, B, L, dx, dtable, dpos):
+    """packed-row form of token_embed_bwd_sorted (``tokens`` = the M packed ids; ``dtable`` zero on entry)"""
+    vocab, C = dtable.shape
+    M = tokens.numel()
+    keys, order = torch.sort(tokens)
+    is16 = dx.dtype == BF16
+    _lib.call("ocn_token_embed_bwd_sorted_varlen", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"),
+              _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"),
+              _chk(seq_off, torch.int32, "seq_off"), B, L, M, C, vocab, _stream())
 
 
 def argmax_rows(text):

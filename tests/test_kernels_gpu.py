@@ -608,3 +608,137 @@ def test_token_embed_backward_sorted_at_bench_size(dev):
     ref = torch.zeros(V, C, device=dev, dtype=torch.float64).index_add_(0, text.reshape(-1), dx.double())
     check("token_embed_bwd_sorted[4096x77x512] dtable", dtable, ref, rel=2e-6)
     check("token_embed_bwd_sorted[4096x77x512] dpos", dpos, dx.reshape(B, L, C).double().sum(0), rel=2e-6)
+
+
+# ---- packed ("varlen") text batches: only the first eot+1 tokens of each sequence exist (ocn_seq_pack_plan & friends) ----------------
+def _random_text(B, L, vocab, g, full_every=0):
+    """SOT, random ids, EOT (= vocab-1, the maximum id) at a random position, zero padding behind it (tokenizer.py:209-226 layout)"""
+    text = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        n = L - 2 if (full_every and b % full_every == 0) else int(torch.randint(0, L - 1, (1,), generator=g))
+        text[b, 0] = vocab - 2
+        text[b, 1:1 + n] = torch.randint(1, vocab - 2, (n,), generator=g)
+        text[b, 1 + n] = vocab - 1
+    return text
+
+
+@pytest.mark.parametrize("B,L", [(7, 77), (4096, 77), (5, 16), (1500, 33)])
+def test_seq_pack_plan_and_rows(dev, B, L):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(B + L)
+    text = _random_text(B, L, 1000, g, full_every=5).to(dev)
+    eot, seq_off, last_row = ops.seq_pack_plan(text)
+    ref_eot = text.argmax(dim=-1)
+    ref_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), (ref_eot + 1).cumsum(0)])
+    assert torch.equal(eot.long(), ref_eot) and torch.equal(seq_off.long(), ref_off) and torch.equal(last_row.long(), ref_off[1:] - 1)
+    M = int(seq_off[-1])
+    tokens, posidx = ops.seq_pack_rows(text, seq_off, M)
+    keep = torch.arange(L, device=dev)[None, :] <= ref_eot[:, None]
+    assert torch.equal(tokens, text[keep]) and torch.equal(posidx.long(), torch.arange(L, device=dev).expand(B, L)[keep])
+    _report(f"seq_pack_plan/rows[B{B} L{L}]: M={M} of {B * L} rows kept, bit-exact vs torch argmax/cumsum/masked_select")
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(6, 77, 3, True), (9, 50, 2, False), (4, 128, 1, True), (5, 20, 2, True), (3, 257, 2, False), (64, 77, 8, True)])
+def test_attention_varlen(dev, B, L, H, causal):
+    """packed batch (sequence b = rows seq_off[b]..seq_off[b+1]) against the dense fp32 reference run per sequence on its own
+    rows; lengths cover 1, exact multiples of 32, L and everything between.  Same tolerances as the dense test."""
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(B * L + H + 5)
+    C = H * 64
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0], lens[-1] = 1, L
+    if B > 2:
+        lens[1] = min(L, 32)
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
+    M = int(off[-1])
+    seq_off = off.to(torch.int32).to(dev)
+    qkv = bf(torch.randn(M, 3 * C, generator=g) * 1.5).to(dev)
+    dout = bf(torch.randn(M, C, generator=g)).to(dev)
+    out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125, seq_off=seq_off)
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, B, L, H, causal, 0.125, seq_off=seq_off)
+    ref_o, ref_d, ref_lse, got_lse = [], [], [], []
+    for b in range(B):
+        r0, n = int(off[b]), int(lens[b])
+        x = qkv[r0:r0 + n].float().requires_grad_(True)
+        o, l = _attn_ref(x, 1, n, H, causal)
+        o.backward(dout[r0:r0 + n].float())
+        ref_o.append(o.detach()); ref_d.append(x.grad); ref_lse.append(l.detach().reshape(H, n))
+        got_lse.append(lse.reshape(B, H, L)[b, :, :n])
+    tag = f"attn_varlen[B{B} Lmax{L} H{H} c{int(causal)} rows {M}/{B * L}]"
+    check(tag + " out", out, torch.cat(ref_o), rel=6e-3)
+    check(tag + " lse", torch.cat([t.reshape(-1) for t in got_lse]), torch.cat([t.reshape(-1) for t in ref_lse]), rel=1e-5)
+    check(tag + " dqkv", dqkv, torch.cat(ref_d), rel=1.5e-2)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all()
+
+
+def test_attention_varlen_equals_dense_when_full(dev):
+    """seq_off = multiples of L must give the dense kernels' results bit for bit (same code path, same order of operations)"""
+    from open_clip_amd import ops
+    B, L, H = 12, 77, 8
+    g = torch.Generator().manual_seed(3)
+    qkv = bf(torch.randn(B * L, 3 * H * 64, generator=g)).to(dev)
+    dout = bf(torch.randn(B * L, H * 64, generator=g)).to(dev)
+    seq_off = (torch.arange(B + 1, dtype=torch.int32) * L).to(dev)
+    o1, l1 = ops.attn_fwd(qkv, B, L, H, True, 0.125)
+    o2, l2 = ops.attn_fwd(qkv, B, L, H, True, 0.125, seq_off=seq_off)
+    d1 = ops.attn_bwd(qkv, o1, dout, l1, B, L, H, True, 0.125)
+    d2 = ops.attn_bwd(qkv, o2, dout, l2, B, L, H, True, 0.125, seq_off=seq_off)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("B,dx_dtype", [(64, torch.float32), (4096, torch.float32), (4096, torch.bfloat16)])
+def test_token_embed_packed(dev, B, dx_dtype):
+    """packed embedding forward (bit-exact: table[token] + pos[l] in fp32) and its segment-reduce backward vs index_add_"""
+    from open_clip_amd import ops
+    L, C, V = 77, 512, 49408
+    g = torch.Generator().manual_seed(B)
+    text = _random_text(B, L, V, g).to(dev)
+    table = torch.randn(V, C, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    pos = torch.randn(L, C, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    eot, seq_off, last_row = ops.seq_pack_plan(text)
+    M = int(seq_off[-1])
+    tokens, posidx = ops.seq_pack_rows(text, seq_off, M)
+    x = ops.token_embed_fwd_rows(tokens, posidx, table, pos)
+    dense = ops.token_embed_fwd(text, table, pos).reshape(B, L, C)
+    keep = torch.arange(L, device=dev)[None, :] <= eot[:, None]
+    assert torch.equal(x, dense[keep])
+    dx = torch.randn(M, C, device=dev, generator=torch.Generator(device=dev).manual_seed(4)).to(dx_dtype)
+    dtable, dpos = torch.zeros(V, C, device=dev), torch.zeros(L, C, device=dev)
+    ops.token_embed_bwd_sorted_varlen(tokens, seq_off, B, L, dx, dtable, dpos)
+    ref_t = torch.zeros(V, C, device=dev, dtype=torch.float64).index_add_(0, tokens, dx.double())
+    ref_p = torch.zeros(L, C, device=dev, dtype=torch.float64).index_add_(0, posidx.long(), dx.double())
+    tag = f"token_embed packed[B{B} rows {M}/{B * L} {str(dx_dtype).split('.')[-1]}]"
+    check(tag + " dtable", dtable, ref_t, rel=2e-6)
+    check(tag + " dpos", dpos, ref_p, rel=2e-6)
+
+
+@pytest.mark.parametrize("M", [177243, 1025])
+def test_gemm_ragged_rows(dev, M):
+    """the persistent GEMMs at a row count that is no multiple of the 256-row tile (what a packed text batch produces), every epilogue
+    of the block, output pre-filled with NaN; and the wgrad over the same ragged M"""
+    from open_clip_amd import ops
+    C = 512
+    g = torch.Generator(device=dev).manual_seed(M)
+    a = bf(torch.randn(M, C, device=dev, generator=g))
+    w = bf(torch.randn(4 * C, C, device=dev, generator=g) * C ** -0.5)
+    bias = torch.randn(4 * C, device=dev, generator=g)
+    out = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    aux = torch.full((M, 4 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.gemm_nt(ops.EPI_BIAS_GELU, a, w, out, bias=bias, aux=aux)
+    tail = slice(max(0, M - 600), M)
+    ref = torch.nn.functional.gelu(a[tail].float() @ w.float().t() + bias)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(aux.float()).all()
+    check(f"gemm_nt ragged M={M} gelu tail rows", out[tail], ref, rel=2.5e-3)
+    resid = torch.randn(M, C, device=dev, generator=g)
+    out2 = torch.full((M, C), float("nan"), device=dev)
+    ops.gemm_nt(ops.EPI_BIAS_RESID_F32, out, bf(w.float().t().contiguous()), out2, bias=bias[:C].contiguous(), resid=resid)
+    ref2 = out[tail].float() @ w.float() + bias[:C] + resid[tail]
+    assert torch.isfinite(out2).all()
+    check(f"gemm_nt ragged M={M} resid tail rows", out2[tail], ref2, rel=2e-5)
+    dw, db = torch.zeros(4 * C, C, device=dev), torch.zeros(4 * C, device=dev)
+    ops.gemm_tn_accum(out, a, dw, db)
+    refw = torch.zeros(4 * C, C, device=dev, dtype=torch.float64)
+    for r0 in range(0, M, 16384):
+        refw += (out[r0:r0 + 16384].float().t() @ a[r0:r0 + 16384].float()).double()
+    check(f"gemm_tn ragged M={M} dW", dw, refw, rel=2e-4)
+    check(f"gemm_tn ragged M={M} dbias", db, out.float().sum(0).double(), rel=2e-4)

@@ -463,3 +463,31 @@ def test_vith14_siglip_full_size_against_cpu_oracle_and_loss_after_one_update():
         r2 = float(O.siglip_loss(ro["image_features"], [ro["text_features"]], ro["logit_scale"], ro["logit_bias"], 0))
     _report(f"oracle[ViT-H-14]: loss after one AdamW update at lr 5e-4: native {l2:.4f} oracle {r2:.4f} (before: {float(outs['loss']):.4f})")
     assert abs(l2 - r2) <= max(5 * LOSS_TOL, 0.03 * abs(r2))
+
+
+def test_packed_text_tower_equals_dense_text_tower():
+    """``pack_text`` (only the tokens up to the pooled EOT exist in the text tower) against the same model running all 77 positions
+    like the reference: identical text features BIT FOR BIT (every kernel works row- / sequence-locally and the causal mask hides
+    the dropped positions), the same loss (its row sums are reduced with fp32 atomics, so two runs of the SAME tower already differ
+    in the last bits: |diff| <= 2e-6 relative), and gradients equal up to the fp32 summation order of the weight-gradient GEMMs
+    (the dense tower adds the dropped rows' exact zeros in a different split).  tolerance: rel-L2 <= 2e-5 per parameter."""
+    cfg = get_model_config("ViT-B-32")
+    state = init_state_dict(cfg, seed=1, perturb=True)
+    batch = synthetic_batch(cfg, 96, seed=11)
+    batch["text"][0, :] = 0
+    batch["text"][0, 0] = cfg["text_cfg"]["vocab_size"] - 1          # EOT first: a one-token sequence
+    batch["text"][1, -1] = cfg["text_cfg"]["vocab_size"] - 1 + 0     # a second maximum at the end: argmax keeps the FIRST one
+    res = {}
+    for mode in (True, False):
+        model = _build(cfg, state)
+        assert model.pack_text, "the packed text tower must be the default on the ViT-B-32 text tower (head_dim 64, L = 77)"
+        model.pack_text = mode
+        out, loss = _step(model, batch)
+        res[mode] = (out, float(loss), {k: p.grad.clone() for k, p in model.named_parameters()})
+    (o1, l1, g1), (o0, l0, g0) = res[True], res[False]
+    assert torch.equal(o1["text_features"], o0["text_features"]), float((o1["text_features"] - o0["text_features"]).abs().max())
+    assert torch.equal(o1["image_features"], o0["image_features"])
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+    worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0)
+    _report(f"packed vs dense text tower (ViT-B-32, B=96): features bit-identical, loss {l1:.7f} vs {l0:.7f}; worst gradient rel_l2 = {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] <= 2e-5, worst

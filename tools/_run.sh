@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-rm -f gpurun_out/parity_report.txt
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r2u_tests.log
+for m in all ln attn none; do
+OCN_WGRAD_PAIR=$m timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eager-baseline > gpurun_out/r2v_pair_$m.log 2>&1
+done
