@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--lr-warmup-steps", type=int, default=10000, help="linear warm-up as the reference schedules it (params.py:288, scheduler.py:6-15)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--serial-towers", action="store_true", help="image and text tower on ONE stream (default: the image tower on a stream of its own next "
+                    "to the text tower, model.py::_TOWER_SIDE; the steps whose GEMM launches carry HIP events always run serially)")
+    ap.add_argument("--no-wgrad-pair", action="store_true", help="with --serial-towers: no wgrad side stream either (every kernel alone on the chip: the "
+                    "configuration of the event-timed steps, used for the rocprofv3 / PMC passes)")
     ap.add_argument("--no-dense-text-line", action="store_true", help="skip the extra --dense-text timing that the default line carries")
     ap.add_argument("--dense-text", action="store_true", help="run all context_length positions of every caption through the text tower like the reference "
                     "does (default: packed -- only the tokens up to the pooled EOT exist; same features, loss and gradients, see model.py::_TextPack)")
@@ -224,6 +228,10 @@ def main():
     model = model.to(dev).train()
     if args.dense_text:
         model.pack_text = False
+    if args.serial_towers:
+        model.tower_streams = False
+    overlap_towers = model.tower_streams
+    model.pair_wgrad = not args.no_wgrad_pair
     if args.grad_checkpointing:
         model.set_grad_checkpointing(True)
     B = args.local_batch
@@ -324,19 +332,34 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Warm-up covers BOTH configurations the timed region uses (the caching allocator keeps one pool per stream: the first one-stream
+    # step allocates the image tower's activations a second time, from the caller's stream's pool -- a one-off that belongs here)
+    for w in range(args.warmup):
+        serial = overlap_towers and (not args.no_roofline) and w == args.warmup - 1 and args.warmup >= 2
+        model.tower_streams = overlap_towers and not serial
         loss = step()
+    model.tower_streams = overlap_towers
+    if overlap_towers and not args.no_roofline:
+        free_b, total_b = torch.cuda.mem_get_info()
+        if free_b < 0.05 * total_b:  # two pools do not fit next to each other: time everything in the one-stream configuration
+            overlap_towers = model.tower_streams = False
     barrier()
-    # GEMM launches carry HIP events on every second timed step (the events cost ~0.8 % of a step when every launch has them)
+    # GEMM launches carry HIP events on every EV-th timed step.  On those steps the towers run on ONE stream with nothing beside a
+    # GEMM, so that a launch's duration is the kernel's own (with the towers overlapped two kernels share the chip and an event
+    # pair times the mix); the other steps run as shipped.  Every step is inside the timed region and counts in ``value``.
+    EV = 10 if overlap_towers else 2
     timed_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        timer.on = (not args.no_roofline) and (i % 2 == 0)
+        timer.on = (not args.no_roofline) and (i % EV == 0)
         timed_steps += int(timer.on)
+        model.tower_streams = overlap_towers and not timer.on
+        model.pair_wgrad = not (overlap_towers and timer.on) and not args.no_wgrad_pair
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    model.tower_streams, model.pair_wgrad = overlap_towers, not args.no_wgrad_pair
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -380,10 +403,11 @@ def main():
                        "ddp": bool(world > 1 or args.force_ddp), "bucket_cap_mb": args.bucket_cap_mb,
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "text_tower": text_rows_note,
+                       "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             # FLOPs of the model as the reference runs it (every caption padded to context_length); the packed text tower executes fewer
             ("step_model_tflops_per_gpu" if not model_ref.pack_text else "step_dense_equivalent_model_tflops_per_gpu"): round(value / world * flops_pair / 1e3, 1),
-            "peak_hbm_gb_rank0": round(peak_bytes / 1e9, 1),
+            "peak_hbm_gb_rank0": round(peak_bytes / 1e9, 1), "reserved_hbm_gb_rank0": round(torch.cuda.max_memory_reserved() / 1e9, 1),
         }
         if dense_text is not None:
             line["dense_text_tower"] = dense_text
@@ -401,10 +425,13 @@ def main():
                                 "algorithmic_tflop_per_launch_avg": round(nt["tflop"] / max(nt["launches"], 1), 4),
                                 "gemm_tn_kernel": {"achieved": round(tn["tflops"], 1), "frac": round(tn["tflops"] / PEAK_BF16_TFLOPS, 4),
                                                    "launches": tn["launches"], "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4),
-                                                   "note": "wgrad launches run on a side stream UNDER the LayerNorm / attention backward kernels of "
-                                                           "their block (model.py::_Paired), so these events time a co-scheduled kernel; alone it "
-                                                           "runs at ~1.2 PFLOP/s (profiles/r01_gemm_shapes.txt, OCN_WGRAD_STREAM=0)"},
+                                                   "note": ("timed alone on the chip (event-timed steps run without the wgrad side stream)" if overlap_towers else
+                                                            "wgrad launches run on a side stream UNDER the LayerNorm / attention backward kernels of "
+                                                            "their block (model.py::_Paired), so these events time a co-scheduled kernel; alone it "
+                                                            "runs at ~1.1-1.2 PFLOP/s (bench.py without --serial-towers times it alone)")},
                                 "event_timed_steps": timed_steps,
+                                "event_timed_steps_mode": ("towers on one stream, no wgrad side stream: every GEMM launch alone on the chip; the other "
+                                                           f"{args.steps - timed_steps} timed steps overlap the towers" if overlap_towers else "as every step"),
                                 "gemm_share_of_step": round((nt["ms"] + tn["ms"]) / (elapsed * 1e3 * timed_steps / args.steps), 3)}
         if world == 1 and not args.no_eager_baseline and not args.siglip:
             micro.clear()

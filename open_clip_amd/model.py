@@ -35,6 +35,7 @@ def _round_up(a, b):
 class _WeightCache:
     def __init__(self):
         self._d = {}
+        self.pair_wgrad = True  # block backward: run the wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
 
     def get(self, p: torch.Tensor, kind: str):
         """kind: 'n' = bf16 copy [rows, cols]; 't' = bf16 transpose [cols, rows] (2-D views of p)"""
@@ -139,12 +140,26 @@ _PAIR_MODE = _os.environ.get("OCN_WGRAD_PAIR", "all")
 
 
 def _side_stream(dev):
+    """the wgrad stream that belongs to the CURRENT stream (one per main stream: the towers may run on streams of their own)"""
     if _os.environ.get("OCN_WGRAD_STREAM", "1") == "0":
         return None
-    st = _SIDE.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    st = _SIDE.get(key)
     if st is None:
-        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
     return st
+
+
+# The two towers are independent until the loss.  With ``tower_streams`` the IMAGE tower runs on a stream of its own (forward and,
+# through autograd's per-node stream bookkeeping, backward) next to the text tower on the caller's stream: the tail of one tower's
+# persistent GEMM (a last round that fills 37-43 % of the CUs at N = 768 / 512) and its HBM-bound kernels are filled by the other
+# tower's launches.  197 -> 188 ms per step (profiles/r02_tower_streams.txt).  The image tower takes the side stream because autograd
+# accumulates every parameter gradient on the stream the accumulator was created on -- under DDP the caller's stream -- behind a
+# wait for the producing node: text-tower nodes (created last, run first in backward) sit on the caller's stream and wait for nothing,
+# the waits for the image tower's blocks queue up behind them.  The per-block wgrad side streams (_Paired) are switched off in this
+# mode (two MFMA-bound streams are enough; measured 191.5 with, 188.1 without).
+_TOWER_STREAMS_DEFAULT = _os.environ.get("OCN_TOWER_STREAMS", "1") != "0"
+_TOWER_SIDE = {}
 
 
 class _Paired:
@@ -238,7 +253,8 @@ class _BlockFn(torch.autograd.Function):
         # ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid)))) ----
         df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
         dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, _PAIR_MODE in ("all", "ln")) as side:
+        pair = cache.pair_wgrad
+        with _Paired(dev, pair and _PAIR_MODE in ("all", "ln")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj)
             # dxmid leaves as a (hi, lo) bf16 pair: hi is the operand of the next two GEMMs, hi + lo the residual gradient that the
@@ -251,12 +267,12 @@ class _BlockFn(torch.autograd.Function):
                 dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, _PAIR_MODE in ("all", "attn")) as side:
+        with _Paired(dev, pair and _PAIR_MODE in ("all", "attn")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
             dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, _PAIR_MODE in ("all", "ln")) as side:
+        with _Paired(dev, pair and _PAIR_MODE in ("all", "ln")) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo)
                 side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv)
@@ -658,6 +674,8 @@ class NativeCLIP(nn.Module):
         # packed text tower (see _TextPack): on by default where the varlen attention kernels apply (head_dim 64, L <= 320);
         # ``model.pack_text = False`` (or OCN_TEXT_PACK=0) runs every one of the context_length positions like the reference does
         self.pack_text = (os.environ.get("OCN_TEXT_PACK", "1") != "0" and t["width"] // t["heads"] == 64 and self.context_length <= 320)
+        self.tower_streams = _TOWER_STREAMS_DEFAULT  # image tower on a stream of its own next to the text tower (see _TOWER_SIDE)
+        self.pair_wgrad = True  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
         # manual re-initialisation) do not move the counter, so every load_state_dict drops them
@@ -742,8 +760,24 @@ class NativeCLIP(nn.Module):
     def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):
         # the packed text layout is planned first: its 4-byte read-back then completes while the image tower is being enqueued
         pack = _TextPack(text) if (text is not None and self.pack_text) else None
-        image_features = self.encode_image(image, normalize=True) if image is not None else None
-        text_features = self.encode_text(text, normalize=True, _pack=pack) if text is not None else None
+        overlap = self.tower_streams and image is not None and text is not None
+        self._cache.pair_wgrad = self.visual._cache.pair_wgrad = self.pair_wgrad and not overlap
+        if overlap:
+            dev = text.device
+            cur = torch.cuda.current_stream(dev)
+            side = _TOWER_SIDE.get(dev)
+            if side is None:
+                side = _TOWER_SIDE[dev] = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                image_features = self.encode_image(image, normalize=True)
+            image.record_stream(side)
+            text_features = self.encode_text(text, normalize=True, _pack=pack)
+            cur.wait_stream(side)
+            image_features.record_stream(cur)
+        else:
+            image_features = self.encode_image(image, normalize=True) if image is not None else None
+            text_features = self.encode_text(text, normalize=True, _pack=pack) if text is not None else None
         if self.output_dict:
             out = {"image_features": image_features, "text_features": text_features, "logit_scale": self.logit_scale.exp()}
             if self.logit_bias is not None:

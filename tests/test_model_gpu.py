@@ -491,3 +491,43 @@ def test_packed_text_tower_equals_dense_text_tower():
     worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0)
     _report(f"packed vs dense text tower (ViT-B-32, B=96): features bit-identical, loss {l1:.7f} vs {l0:.7f}; worst gradient rel_l2 = {worst[0]:.3e} ({worst[1]})")
     assert worst[0] <= 2e-5, worst
+
+
+def test_overlapped_towers_equal_one_stream():
+    """``tower_streams`` (image tower on a stream of its own next to the text tower, forward and backward) against the same model on
+    one stream: bit-identical features, and over four optimizer steps -- allocator reuse across the two streams, the bf16 weight
+    copies the optimizer rewrites, the packed-text plan -- the same loss trajectory (fp32 atomics reorder the weight-gradient sums:
+    rel <= 2e-5 on gradients, 1e-5 on the loss) and final parameters (rel <= 3e-3: Adam turns the rounding noise of gradients that are
+    mathematically zero, e.g. the key bias of every attention layer, into +-lr steps)."""
+    from open_clip_amd.loss import NativeClipLoss
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
+    cfg = get_model_config("ViT-B-32")
+    state = init_state_dict(cfg, seed=2, perturb=True)
+    batches = [synthetic_batch(cfg, 128, seed=20 + i, device="cuda") for i in range(4)]
+    res = {}
+    for mode in (True, False):
+        model = _build(cfg, state)
+        assert model.tower_streams, "overlapped towers must be the default"
+        model.tower_streams = mode
+        opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
+        loss_fn, losses, first = NativeClipLoss(), [], None
+        for b in batches:
+            opt.zero_grad(set_to_none=True)
+            out = model(image=b["image"], text=b["text"])
+            loss = loss_fn(**out)
+            loss.backward()
+            if first is None:
+                first = (out["image_features"].clone(), out["text_features"].clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+            opt.step()
+            losses.append(float(loss.detach()))
+            del out, loss  # the next step reuses this step's memory while the other stream may still be draining
+        torch.cuda.synchronize()
+        res[mode] = (first, losses, {k: p.detach().clone() for k, p in model.named_parameters()})
+    (f1, l1, p1), (f0, l0, p0) = res[True], res[False]
+    assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])
+    gw = max((float((f1[2][k] - f0[2][k]).norm() / (f0[2][k].norm() + 1e-30)), k) for k in f0[2])
+    lw = max(abs(a - b) / abs(b) for a, b in zip(l1, l0))
+    pw = max((float((p1[k] - p0[k]).norm() / (p0[k].norm() + 1e-30)), k) for k in p0)
+    _report(f"overlapped vs one-stream towers (ViT-B-32, B=128, 4 AdamW steps): features bit-identical; worst gradient rel_l2 {gw[0]:.2e} ({gw[1]}), "
+            f"loss trajectory rel {lw:.2e} {['%.5f' % v for v in l1]}, final parameters rel_l2 {pw[0]:.2e} ({pw[1]})")
+    assert gw[0] <= 2e-5 and lw <= 1e-5 and pw[0] <= 3e-3, (gw, lw, pw)

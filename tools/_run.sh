@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for m in all ln attn none; do
-OCN_WGRAD_PAIR=$m timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eager-baseline > gpurun_out/r2v_pair_$m.log 2>&1
-done
+rm -f gpurun_out/parity_report.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r2z_tests.log
+cp gpurun_out/parity_report.txt gpurun_out/r2z_parity_report.txt 2>/dev/null
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eager-baseline > gpurun_out/r2z_bench.log 2>&1
