@@ -274,6 +274,10 @@ def main():
     if world > 1 or args.force_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_cap_mb, gradient_as_bucket_view=True)
 
+    import warnings
+    # alternating between the one-stream (event-timed) and the two-stream steps leaves gradient accumulators behind that were created
+    # on the other stream; autograd synchronises them correctly and says so once
+    warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
     timer = GemmTimer()
     if not args.no_roofline:
         timer.install()

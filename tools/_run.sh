@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-rm -f gpurun_out/parity_report.txt
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r2z_tests.log
-cp gpurun_out/parity_report.txt gpurun_out/r2z_parity_report.txt 2>/dev/null
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eager-baseline > gpurun_out/r2z_bench.log 2>&1
+B="--steps 10 --warmup 4 --no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-roofline"
+OCN_IMAGE_SPLIT=1 timeout 300 python bench.py $B > gpurun_out/r2s_1.log 2>&1
+OCN_IMAGE_SPLIT=2 timeout 300 python bench.py $B > gpurun_out/r2s_2.log 2>&1
+OCN_IMAGE_SPLIT=3 timeout 300 python bench.py $B > gpurun_out/r2s_3.log 2>&1
