@@ -274,10 +274,6 @@ def main():
     if world > 1 or args.force_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_cap_mb, gradient_as_bucket_view=True)
 
-    import warnings
-    # alternating between the one-stream (event-timed) and the two-stream steps leaves gradient accumulators behind that were created
-    # on the other stream; autograd synchronises them correctly and says so once
-    warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
     timer = GemmTimer()
     if not args.no_roofline:
         timer.install()
@@ -336,34 +332,26 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up covers BOTH configurations the timed region uses (the caching allocator keeps one pool per stream: the first one-stream
-    # step allocates the image tower's activations a second time, from the caller's stream's pool -- a one-off that belongs here)
     for w in range(args.warmup):
-        serial = overlap_towers and (not args.no_roofline) and w == args.warmup - 1 and args.warmup >= 2
-        model.tower_streams = overlap_towers and not serial
         loss = step()
-    model.tower_streams = overlap_towers
-    if overlap_towers and not args.no_roofline:
-        free_b, total_b = torch.cuda.mem_get_info()
-        if free_b < 0.05 * total_b:  # two pools do not fit next to each other: time everything in the one-stream configuration
-            overlap_towers = model.tower_streams = False
     barrier()
-    # GEMM launches carry HIP events on every EV-th timed step.  On those steps the towers run on ONE stream with nothing beside a
-    # GEMM, so that a launch's duration is the kernel's own (with the towers overlapped two kernels share the chip and an event
-    # pair times the mix); the other steps run as shipped.  Every step is inside the timed region and counts in ``value``.
+    # GEMM launches carry HIP events on every EV-th timed step.  On those steps the towers run ONE AT A TIME (model.tower_streams =
+    # "serial": the same two streams and allocator pools as the shipped configuration, the image tower's stream held back behind the
+    # text tower's in forward and backward) with nothing beside a GEMM, so that a launch's duration is the kernel's own (with the
+    # towers overlapped two kernels share the chip and an event pair times the mix); the other steps run as shipped.  Every step is
+    # inside the timed region and counts in ``value``.
     EV = 10 if overlap_towers else 2
     timed_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         timer.on = (not args.no_roofline) and (i % EV == 0)
         timed_steps += int(timer.on)
-        model.tower_streams = overlap_towers and not timer.on
-        model.pair_wgrad = not (overlap_towers and timer.on) and not args.no_wgrad_pair
+        model.tower_streams = ("serial" if timer.on else True) if overlap_towers else False
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
     timer.on = False
-    model.tower_streams, model.pair_wgrad = overlap_towers, not args.no_wgrad_pair
+    model.tower_streams = overlap_towers
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -434,8 +422,9 @@ def main():
                                                             "their block (model.py::_Paired), so these events time a co-scheduled kernel; alone it "
                                                             "runs at ~1.1-1.2 PFLOP/s (bench.py without --serial-towers times it alone)")},
                                 "event_timed_steps": timed_steps,
-                                "event_timed_steps_mode": ("towers on one stream, no wgrad side stream: every GEMM launch alone on the chip; the other "
-                                                           f"{args.steps - timed_steps} timed steps overlap the towers" if overlap_towers else "as every step"),
+                                "event_timed_steps_mode": ("one tower at a time (same two streams, the image tower's held back behind the text tower's), no wgrad "
+                                                           f"side stream: every GEMM launch alone on the chip; the other {args.steps - timed_steps} timed steps "
+                                                           "overlap the towers" if overlap_towers else "as every step"),
                                 "gemm_share_of_step": round((nt["ms"] + tn["ms"]) / (elapsed * 1e3 * timed_steps / args.steps), 3)}
         if world == 1 and not args.no_eager_baseline and not args.siglip:
             micro.clear()

@@ -22,6 +22,8 @@
 // ds_write_b64/b128, and stores whole 128-byte rows.
 #include "gemm_args.h"
 
+#include <type_traits>
+
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -245,24 +247,33 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
             return ((unsigned)(row * a.ldc + gn) * esz) | colmask[hb];
         };
-        auto load_ex = [&](int blk, f32x4 (&ex)[4]) {
+        // Epilogue operands (residual rows / saved gelu') sit in a ring of DEPTH blocks: block k + DEPTH - 1 is requested before the
+        // stores of block k are issued.  vmcnt retires loads AND stores in issue order, so waiting for block k's operand also waits
+        // for every store issued before its request: with DEPTH = 2 that is the stores of block k - 2, whose HBM acknowledgement is
+        // what the epilogue then idles on.  AUX bit 5 (32) deepens the ring: the dGELU epilogue (8 bytes per lane and row) requests
+        // ALL eight blocks before its first store (64 VGPRs, no wait ever sits behind a store), the fp32 residual (16 bytes) runs
+        // four blocks ahead (64 VGPRs).
+        constexpr int DEPTH = !HAS_EX ? 1 : ((AUX & 32) ? (EPI == OCN_EPI_DGELU ? 8 : 4) : 2);
+        typedef typename std::conditional<EPI == OCN_EPI_DGELU, bf16x4, f32x4>::type ex_t;
+        ex_t ex[DEPTH][4];
+        auto load_ex = [&](int blk, ex_t (&e)[4]) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                if (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    ex[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
-                } else if (EPI == OCN_EPI_DGELU) {
-                    const bf16x4 p4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_aux, byte_off(blk, it, 2u), 0, (AUX & 8) ? 2 : 0));
-                    ex[it] = (f32x4){bf2f(p4[0]), bf2f(p4[1]), bf2f(p4[2]), bf2f(p4[3])};
+                if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
+                    e[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
+                } else if constexpr (EPI == OCN_EPI_DGELU) {
+                    e[it] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_aux, byte_off(blk, it, 2u), 0, (AUX & 8) ? 2 : 0));
                 }
             }
         };
-        f32x4 exA[4], exB[4];
-        if (HAS_EX) load_ex(0, exA);
+        if constexpr (HAS_EX) {
+#pragma unroll
+            for (int b = 0; b < DEPTH - 1; ++b) load_ex(b, ex[b]);
+        }
 #pragma unroll
         for (int blk = 0; blk < 8; ++blk) {
             const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
             if (dbg && blk == 4) dbg[6] = wall_clock64();
-            f32x4 (&ex)[4] = (blk & 1) ? exB : exA;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
@@ -270,15 +281,17 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             }
             f32x4 d[4];
             lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
-            if (HAS_EX && blk + 1 < 8) load_ex(blk + 1, (blk & 1) ? exA : exB);
+            if constexpr (HAS_EX) {
+                if (blk + DEPTH - 1 < 8) load_ex(blk + DEPTH - 1, ex[(blk + DEPTH - 1) % DEPTH]);
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
-                if (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[it]), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
-                } else if (EPI == OCN_EPI_DGELU) {
-                    const f32x4 dg = ex[it];  // gelu'(pre-activation), saved by the forward epilogue
-                    const bf16x4 o4 = {f2bf(v[0] * dg[0]), f2bf(v[1] * dg[1]), f2bf(v[2] * dg[2]), f2bf(v[3] * dg[3])};
+                if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[blk % DEPTH][it]), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
+                } else if constexpr (EPI == OCN_EPI_DGELU) {
+                    const bf16x4 p4 = ex[blk % DEPTH][it];  // gelu'(pre-activation), saved by the forward epilogue
+                    const bf16x4 o4 = {f2bf(v[0] * bf2f(p4[0])), f2bf(v[1] * bf2f(p4[1])), f2bf(v[2] * bf2f(p4[2])), f2bf(v[3] * bf2f(p4[3]))};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u) & omask, 0, AUX & 2);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
@@ -577,6 +590,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 }
 
 int g_num_cu = 0;
+#ifndef OCN_NT5_DEEP_RING
+#define OCN_NT5_DEEP_RING true  // shipped default of AUX bit 5 (A/B: tools/ab_deep_ring.py, profiles/r02_deep_operand_ring.txt)
+#endif
 }  // namespace
 extern int g_ocn_tuning[16];
 namespace {
@@ -654,7 +670,10 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     //           epilogue is better left cacheable (-5 % otherwise).
     const bool st_nt = (EPI == OCN_EPI_BIAS_GELU) || (EPI == OCN_EPI_BF16 && a.N >= 1024);
     const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32);
-    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0) | ((a.ablate & 16) ? 16 : 0);
+    // bit 5 (32): deep operand ring of the dGELU / fp32-residual epilogues (see epilogue5); developer knob 0x100000 flips it
+    constexpr bool has_ex = (EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32);
+    const bool deep = has_ex && (OCN_NT5_DEEP_RING != ((a.ablate & 0x100000) != 0));
+    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0) | ((a.ablate & 16) ? 16 : 0) | (deep ? 32 : 0);
 #define OCN_NT5_LAUNCH_AUX(AUXV)                                                                                                   \
     if (aux == (AUXV)) {                                                                                                           \
         static bool set_ = false;                                                                                                  \
@@ -672,6 +691,10 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     OCN_NT5_LAUNCH_AUX(16)
     OCN_NT5_LAUNCH_AUX(18)
     OCN_NT5_LAUNCH_AUX(24)
+    if constexpr (has_ex) {
+        OCN_NT5_LAUNCH_AUX(32)
+        OCN_NT5_LAUNCH_AUX(40)
+    }
 #undef OCN_NT5_LAUNCH_AUX
     static bool attr_set = false;
     if (!attr_set) {

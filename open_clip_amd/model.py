@@ -162,6 +162,24 @@ _TOWER_STREAMS_DEFAULT = _os.environ.get("OCN_TOWER_STREAMS", "1") != "0"
 _TOWER_SIDE = {}
 
 
+class _AfterStream(torch.autograd.Function):
+    """identity whose BACKWARD makes its own stream wait for ``other``.  ``tower_streams = "serial"`` (measurement mode of bench.py: every
+    kernel alone on the chip, but each tower on the stream -- and therefore in the caching-allocator pool -- it uses when the towers
+    overlap) puts it on the image features: the autograd engine runs the text tower's nodes first (created later = higher sequence
+    numbers), all of them on the caller's stream, so when this node runs the whole text backward is enqueued there and the image
+    tower's backward on the side stream starts behind it."""
+
+    @staticmethod
+    def forward(ctx, x, other):
+        ctx.other = other
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.cuda.current_stream(g.device).wait_stream(ctx.other)
+        return g, None
+
+
 class _Paired:
     """``with _Paired(dev) as side: side(fn, ...)`` enqueues fn on the side stream after everything already on the main
     stream; leaving the block joins the side stream back into the main stream."""
@@ -674,7 +692,9 @@ class NativeCLIP(nn.Module):
         # packed text tower (see _TextPack): on by default where the varlen attention kernels apply (head_dim 64, L <= 320);
         # ``model.pack_text = False`` (or OCN_TEXT_PACK=0) runs every one of the context_length positions like the reference does
         self.pack_text = (os.environ.get("OCN_TEXT_PACK", "1") != "0" and t["width"] // t["heads"] == 64 and self.context_length <= 320)
-        self.tower_streams = _TOWER_STREAMS_DEFAULT  # image tower on a stream of its own next to the text tower (see _TOWER_SIDE)
+        # True: image tower on a stream of its own next to the text tower (see _TOWER_SIDE); False: one stream; "serial": the same two
+        # streams, one tower at a time (bench.py's event-timed steps)
+        self.tower_streams = _TOWER_STREAMS_DEFAULT
         self.pair_wgrad = True  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
@@ -768,10 +788,15 @@ class NativeCLIP(nn.Module):
             side = _TOWER_SIDE.get(dev)
             if side is None:
                 side = _TOWER_SIDE[dev] = torch.cuda.Stream(device=dev)
+            serial = self.tower_streams == "serial"  # one tower at a time, on the same two streams (see _AfterStream)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 image_features = self.encode_image(image, normalize=True)
+                if serial and image_features.requires_grad:
+                    image_features = _AfterStream.apply(image_features, cur)
             image.record_stream(side)
+            if serial:
+                cur.wait_stream(side)
             text_features = self.encode_text(text, normalize=True, _pack=pack)
             cur.wait_stream(side)
             image_features.record_stream(cur)

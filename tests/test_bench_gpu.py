@@ -16,13 +16,14 @@ COMMON = ["--model", "small-test", "--local-batch", "8", "--steps", "3", "--warm
           "--lr", "1e-3", "--lr-warmup-steps", "1"]
 
 
-def _bench(extra, nproc=1, env=None):
+def _bench(extra, nproc=1, env=None, roofline=False):
     e = dict(os.environ, **(env or {}))
+    common = [a for a in COMMON if roofline is False or a != "--no-roofline"]
     if nproc == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON + extra
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common + extra
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29741",
-               os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + COMMON + extra
+               os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + common + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -31,11 +32,25 @@ def _bench(extra, nproc=1, env=None):
 
 
 def test_bench_world2_reports_the_full_batch_loss():
-    two = _bench(["--dist-backend", "gloo"], nproc=2, env={"OCN_BENCH_ONE_DEVICE": "1"})
+    # roofline=True: as the driver launches it -- the first timed step carries HIP events on every GEMM and runs the towers one at a time
+    # (model.tower_streams = "serial"), the others overlap them; all of it under DistributedDataParallel
+    two = _bench(["--dist-backend", "gloo"], nproc=2, env={"OCN_BENCH_ONE_DEVICE": "1"}, roofline=True)
+    assert two["roofline"]["event_timed_steps"] == 1 and two["roofline"]["launches"] > 0 and two["roofline"]["gemm_tn_kernel"]["launches"] > 0
     one = _bench(["--data-ranks", "2"])
     assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 16 and one["config"]["global_batch"] == 16
     assert "row-sharded" in two["config"]["workload"]
     assert abs(two["config"]["final_loss"] - one["config"]["final_loss"]) < 3e-2, (two["config"]["final_loss"], one["config"]["final_loss"])
+
+
+def test_bench_default_line_mixes_event_timed_and_overlapped_steps():
+    """the default line (roofline on): step 0 of the timed region is event-timed with the towers one at a time, steps 1.. overlap them;
+    the loss after the three optimizer steps must be the one of the run without events / without the stream switch"""
+    with_ev = _bench(["--no-dense-text-line"], roofline=True)
+    without = _bench(["--no-dense-text-line"])
+    r = with_ev["roofline"]
+    assert r["event_timed_steps"] == 1 and r["launches"] > 0 and r["achieved"] > 0 and "one tower at a time" in r["event_timed_steps_mode"]
+    assert abs(with_ev["config"]["final_loss"] - without["config"]["final_loss"]) < 2e-3, (with_ev["config"]["final_loss"], without["config"]["final_loss"])
+    assert with_ev["reserved_hbm_gb_rank0"] <= 1.5 * without["reserved_hbm_gb_rank0"] + 0.5  # one allocator pool per stream in BOTH kinds of step
 
 
 def test_bench_accumulation_and_host_fed_modes():

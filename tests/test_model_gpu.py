@@ -505,9 +505,9 @@ def test_overlapped_towers_equal_one_stream():
     state = init_state_dict(cfg, seed=2, perturb=True)
     batches = [synthetic_batch(cfg, 128, seed=20 + i, device="cuda") for i in range(4)]
     res = {}
-    for mode in (True, False):
+    for mode in (True, "serial", False):
         model = _build(cfg, state)
-        assert model.tower_streams, "overlapped towers must be the default"
+        assert model.tower_streams is True, "overlapped towers must be the default"
         model.tower_streams = mode
         opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
         loss_fn, losses, first = NativeClipLoss(), [], None
@@ -523,11 +523,13 @@ def test_overlapped_towers_equal_one_stream():
             del out, loss  # the next step reuses this step's memory while the other stream may still be draining
         torch.cuda.synchronize()
         res[mode] = (first, losses, {k: p.detach().clone() for k, p in model.named_parameters()})
-    (f1, l1, p1), (f0, l0, p0) = res[True], res[False]
-    assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])
-    gw = max((float((f1[2][k] - f0[2][k]).norm() / (f0[2][k].norm() + 1e-30)), k) for k in f0[2])
-    lw = max(abs(a - b) / abs(b) for a, b in zip(l1, l0))
-    pw = max((float((p1[k] - p0[k]).norm() / (p0[k].norm() + 1e-30)), k) for k in p0)
-    _report(f"overlapped vs one-stream towers (ViT-B-32, B=128, 4 AdamW steps): features bit-identical; worst gradient rel_l2 {gw[0]:.2e} ({gw[1]}), "
-            f"loss trajectory rel {lw:.2e} {['%.5f' % v for v in l1]}, final parameters rel_l2 {pw[0]:.2e} ({pw[1]})")
-    assert gw[0] <= 2e-5 and lw <= 2e-4 and pw[0] <= 3e-3, (gw, lw, pw)
+    f0, l0, p0 = res[False]
+    for mode, what in ((True, "overlapped"), ("serial", "one-at-a-time on two streams (bench.py's event-timed steps)")):
+        f1, l1, p1 = res[mode]
+        assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])
+        gw = max((float((f1[2][k] - f0[2][k]).norm() / (f0[2][k].norm() + 1e-30)), k) for k in f0[2])
+        lw = max(abs(a - b) / abs(b) for a, b in zip(l1, l0))
+        pw = max((float((p1[k] - p0[k]).norm() / (p0[k].norm() + 1e-30)), k) for k in p0)
+        _report(f"{what} vs one-stream towers (ViT-B-32, B=128, 4 AdamW steps): features bit-identical; worst gradient rel_l2 {gw[0]:.2e} ({gw[1]}), "
+                f"loss trajectory rel {lw:.2e} {['%.5f' % v for v in l1]}, final parameters rel_l2 {pw[0]:.2e} ({pw[1]})")
+        assert gw[0] <= 2e-5 and lw <= 2e-4 and pw[0] <= 3e-3, (mode, gw, lw, pw)
