@@ -157,6 +157,9 @@ int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* orde
  * token_embed_fwd_rows: x[r,:] = table[tokens[r]] + pos[posidx[r]] (fp32 [M,C]).
  * token_embed_bwd_sorted_varlen: ocn_token_embed_bwd_sorted over the M packed rows (sorted_tokens / order index packed rows). */
 int ocn_seq_pack_plan(const int64_t* text, int32_t* eot, int32_t* seq_off, int32_t* last_row, int B, int L, ocn_stream_t stream);
+/* *bad_count = number of ids outside [0, vocab) among text[0..n) (one workgroup, no atomics; written, not accumulated).  The embedding
+ * kernels clamp such ids; nn.Embedding (src/open_clip/model.py:399) raises on them -- the host raises from this count. */
+int ocn_token_range_check(const int64_t* text, long n, int vocab, int32_t* bad_count, ocn_stream_t stream);
 int ocn_seq_pack_rows(const int64_t* text, const int32_t* seq_off, int64_t* tokens, int32_t* posidx, int B, int L, ocn_stream_t stream);
 int ocn_token_embed_fwd_rows(const int64_t* tokens, const int32_t* posidx, const float* table, const float* pos, float* x, long M, int C,
                              int vocab, ocn_stream_t stream);

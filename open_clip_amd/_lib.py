@@ -39,6 +39,7 @@ SIGNATURES = {
     "ocn_token_embed_bwd_sorted": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
     "ocn_seq_pack_plan": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_seq_pack_rows": [_p, _p, _p, _p, _i, _i, _p],
+    "ocn_token_range_check": [_p, _l, _i, _p, _p],
     "ocn_token_embed_fwd_rows": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ocn_token_embed_bwd_sorted_varlen": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],

@@ -537,6 +537,34 @@ extern "C" int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const in
     return OCN_OK;
 }
 
+// nn.Embedding raises on ids outside [0, vocab) (model.py:399 -> torch embedding); the embedding kernels here clamp so that a bad id can
+// never read outside the table, and this one-workgroup pass COUNTS such ids so that the host can raise like the reference does
+// (open_clip_amd/model.py::_TextPack reads the count back with the packed row count it waits for anyway).
+__global__ __launch_bounds__(1024) void token_range_kernel(const int64_t* __restrict__ text, long n, int vocab, int32_t* __restrict__ bad) {
+    __shared__ int wsum[16];
+    int c = 0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const long t = text[i];
+        c += (t < 0 || t >= vocab) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        *bad = t;
+    }
+}
+
+extern "C" int ocn_token_range_check(const int64_t* text, long n, int vocab, int32_t* bad_count, ocn_stream_t stream) {
+    OCN_CHECK_ARG(text && bad_count && n > 0 && vocab > 0, "ocn_token_range_check: bad arguments");
+    hipLaunchKernelGGL(token_range_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, text, n, vocab, bad_count);
+    OCN_CHECK_LAUNCH("ocn_token_range_check");
+    return OCN_OK;
+}
+
 extern "C" int ocn_seq_pack_plan(const int64_t* text, int32_t* eot, int32_t* seq_off, int32_t* last_row, int B, int L, ocn_stream_t stream) {
     OCN_CHECK_ARG(text && eot && seq_off && last_row && B > 0 && L > 0, "ocn_seq_pack_plan: bad arguments");
     OCN_CHECK_ARG((long)B * L < 0x7fffffffL, "ocn_seq_pack_plan: B*L = %ld rows exceed int32 offsets", (long)B * L);

@@ -230,13 +230,24 @@ def token_embed_bwd_sorted(text, dx, dtable, dpos):
               _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
 
 
-def seq_pack_plan(text):
-    """(eot [B], seq_off [B+1], last_row [B]) int32 on the device: the packed layout of a text batch (ocn_seq_pack_plan)"""
+def seq_pack_plan(text, vocab=None):
+    """(eot [B], seq_off [B+1(+1)], last_row [B]) int32 on the device: the packed layout of a text batch (ocn_seq_pack_plan).  With
+    ``vocab`` the plan carries one more entry, seq_off[B+1] = the number of ids outside [0, vocab) (ocn_token_range_check)"""
     B, L = text.shape
-    eot, seq_off, last_row = empty((B,), torch.int32, text), empty((B + 1,), torch.int32, text), empty((B,), torch.int32, text)
+    n_off = B + 1 + (1 if vocab is not None else 0)
+    eot, seq_off, last_row = empty((B,), torch.int32, text), empty((n_off,), torch.int32, text), empty((B,), torch.int32, text)
     _lib.call("ocn_seq_pack_plan", _chk(text, torch.int64, "text"), _chk(eot, torch.int32, "eot"), _chk(seq_off, torch.int32, "seq_off"),
               _chk(last_row, torch.int32, "last_row"), B, L, _stream())
+    if vocab is not None:
+        _lib.call("ocn_token_range_check", text.data_ptr(), B * L, int(vocab), seq_off.data_ptr() + 4 * (B + 1), _stream())
     return eot, seq_off, last_row
+
+
+def token_range_check(text, vocab):
+    """int32 [1] on the device: how many ids of ``text`` lie outside [0, vocab)"""
+    bad = empty((1,), torch.int32, text)
+    _lib.call("ocn_token_range_check", _chk(text, torch.int64, "text"), text.numel(), int(vocab), _chk(bad, torch.int32, "bad"), _stream())
+    return bad
 
 
 def seq_pack_rows(text, seq_off, M):

@@ -505,10 +505,13 @@ def test_overlapped_towers_equal_one_stream():
     state = init_state_dict(cfg, seed=2, perturb=True)
     batches = [synthetic_batch(cfg, 128, seed=20 + i, device="cuda") for i in range(4)]
     res = {}
-    for mode in (True, "serial", False):
+    for mode in (True, "interleaved", "paced", "serial", False):
         model = _build(cfg, state)
         assert model.tower_streams is True, "overlapped towers must be the default"
-        model.tower_streams = mode
+        if mode in ("interleaved", "paced"):  # two streams, the towers' blocks enqueued alternately (+ _Pace's events)
+            model.tower_order = mode
+        else:
+            model.tower_streams, model.tower_order = mode, "sequential"
         opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
         loss_fn, losses, first = NativeClipLoss(), [], None
         for b in batches:
@@ -524,7 +527,8 @@ def test_overlapped_towers_equal_one_stream():
         torch.cuda.synchronize()
         res[mode] = (first, losses, {k: p.detach().clone() for k, p in model.named_parameters()})
     f0, l0, p0 = res[False]
-    for mode, what in ((True, "overlapped"), ("serial", "one-at-a-time on two streams (bench.py's event-timed steps)")):
+    for mode, what in ((True, "overlapped"), ("interleaved", "overlapped, blocks enqueued alternately"), ("paced", "overlapped, alternately + paced by events"),
+                       ("serial", "one-at-a-time on two streams (bench.py's event-timed steps)")):
         f1, l1, p1 = res[mode]
         assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])
         gw = max((float((f1[2][k] - f0[2][k]).norm() / (f0[2][k].norm() + 1e-30)), k) for k in f0[2])
@@ -533,3 +537,24 @@ def test_overlapped_towers_equal_one_stream():
         _report(f"{what} vs one-stream towers (ViT-B-32, B=128, 4 AdamW steps): features bit-identical; worst gradient rel_l2 {gw[0]:.2e} ({gw[1]}), "
                 f"loss trajectory rel {lw:.2e} {['%.5f' % v for v in l1]}, final parameters rel_l2 {pw[0]:.2e} ({pw[1]})")
         assert gw[0] <= 2e-5 and lw <= 2e-4 and pw[0] <= 3e-3, (mode, gw, lw, pw)
+
+
+def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
+    """the reference's ``nn.Embedding`` (model.py:399) raises on an id outside [0, vocab_size); the native embedding kernels clamp (no
+    read outside the table) and the packed-text plan counts such ids on the device, so the forward raises IndexError from the 8-byte
+    read-back it waits for anyway (ocn_token_range_check); a clean batch passes, and the kernel's count is exact"""
+    from open_clip_amd import ops
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=3, perturb=True)
+    model = _build(cfg, state)
+    batch = synthetic_batch(cfg, 6, seed=5, device="cuda")
+    model(image=batch["image"], text=batch["text"])  # clean
+    V = cfg["text_cfg"]["vocab_size"]
+    assert int(ops.token_range_check(batch["text"], V)) == 0
+    bad = batch["text"].clone()
+    bad[1, 2], bad[4, 1], bad[5, 3] = V, -1, V + 12345
+    assert int(ops.token_range_check(bad, V)) == 3
+    with pytest.raises(IndexError, match="3 token id"):
+        model(image=batch["image"], text=bad)
+    with pytest.raises(IndexError):
+        model.encode_text(bad, normalize=True)

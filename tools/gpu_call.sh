@@ -7,7 +7,7 @@ has() { case " $STEPS " in *" $1 "*) return 0;; esac; return 1; }
 t0=$(date +%s); stamp() { echo "$1 done at +$(( $(date +%s) - t0 )) s" >> $O/${TAG}_timeline.txt; }
 if has quick; then
   rm -f $O/parity_report.txt
-  timeout 600 python -m pytest tests/test_bench_gpu.py "tests/test_model_gpu.py::test_overlapped_towers_equal_one_stream" tests/test_gemm_bench_shapes_gpu.py -k "not (qkv or c_fc or dh2 or da or dh1 or tn_at)" -x -q --durations=8 2>&1 | tail -25 > $O/${TAG}_tests.log
+  timeout 600 python -m pytest ${QUICK_TESTS:-tests/test_bench_gpu.py tests/test_model_gpu.py::test_overlapped_towers_equal_one_stream} -x -q --durations=8 2>&1 | tail -25 > $O/${TAG}_tests.log
   cp $O/parity_report.txt $O/${TAG}_parity_report.txt 2>/dev/null
   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 > $O/${TAG}_smoke.log; stamp quick
 fi
@@ -22,6 +22,14 @@ if has ab; then
   for V in 0 268435456; do
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --gemm-variant $V 2>&1 | grep '^{' > $O/${TAG}_bench_variant_$V.json
   done; stamp ab
+fi
+if has order; then  # how the two tower streams are fed: A/B/C in one process each, same box
+  for ORD in sequential interleaved paced sequential paced; do
+    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tower-order $ORD 2>&1 | grep '^{' >> $O/${TAG}_order_$ORD.json
+  done
+  for ORD in sequential paced; do
+    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tower-order $ORD --force-ddp 2>&1 | grep '^{' >> $O/${TAG}_order_ddp_$ORD.json
+  done; stamp order
 fi
 if has bench; then timeout 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
 if has lines; then
