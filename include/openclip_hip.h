@@ -114,11 +114,16 @@ int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dout, const fl
 /* Packed ("varlen") batches, head_dim 64.  The text tower pools x[b, argmax(text[b])] (transformer.py:941-944) under the causal
  * mask (:1716-1722), so the tokens behind the pooled one cannot influence the feature or any gradient: the native text tower keeps
  * only the first eot[b]+1 tokens of each sequence.  Sequence b owns rows seq_off[b] .. seq_off[b+1] of qkv / out / dout / dqkv
- * (seq_off: B+1 ascending int32 on the device, 1 <= length <= Lmax <= 320); lse keeps the dense fp32 [B,H,Lmax] layout. */
-int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* seq_off, int B, int Lmax, int H, int causal, float scale,
+ * (seq_off: B+1 ascending int32 on the device, 1 <= length <= Lmax <= 320); lse keeps the dense fp32 [B,H,Lmax] layout.
+ * Bucketing (optional; both pointers or neither): `order` = the B sequence ids grouped by ceil(length / 32) ascending (DEVICE, from
+ * ocn_seq_bucket_plan), `bucket_counts` = how many sequences each group holds (HOST array of ceil(Lmax / 32) ints summing to B).  One
+ * launch per non-empty group, its workgroups sized for that group's length instead of Lmax (these kernels are latency-bound: their
+ * rate is the number of resident workgroups); results do not depend on the bucketing. */
+int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* seq_off, const int32_t* order, const int32_t* bucket_counts,
+                        int B, int Lmax, int H, int causal, float scale, ocn_stream_t stream);
+int ocn_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off,
+                        const int32_t* order, const int32_t* bucket_counts, int B, int Lmax, int H, int causal, float scale,
                         ocn_stream_t stream);
-int ocn_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off, int B,
-                        int Lmax, int H, int causal, float scale, ocn_stream_t stream);
 
 /* ---- image tower embedding (transformer.py:793-808) -------------------------------------------
  * patchify: image [B,3,H,W] (fp32, or bf16 when image_is_bf16) -> patches bf16 [B*gh*gw, Kpad], column order
@@ -160,6 +165,9 @@ int ocn_seq_pack_plan(const int64_t* text, int32_t* eot, int32_t* seq_off, int32
 /* *bad_count = number of ids outside [0, vocab) among text[0..n) (one workgroup, no atomics; written, not accumulated).  The embedding
  * kernels clamp such ids; nn.Embedding (src/open_clip/model.py:399) raises on them -- the host raises from this count. */
 int ocn_token_range_check(const int64_t* text, long n, int vocab, int32_t* bad_count, ocn_stream_t stream);
+/* order[0..B) = sequence ids grouped by ceil(length / 32) ascending, counts[k] = number of sequences with ceil(length / 32) == k + 1
+ * (ceil(Lmax / 32) <= 16 entries, device): the buckets of ocn_attn_{fwd,bwd}_varlen.  The order inside a bucket is unspecified. */
+int ocn_seq_bucket_plan(const int32_t* seq_off, int32_t* order, int32_t* counts, int B, int Lmax, ocn_stream_t stream);
 int ocn_seq_pack_rows(const int64_t* text, const int32_t* seq_off, int64_t* tokens, int32_t* posidx, int B, int L, ocn_stream_t stream);
 int ocn_token_embed_fwd_rows(const int64_t* tokens, const int32_t* posidx, const float* table, const float* pos, float* x, long M, int C,
                              int vocab, ocn_stream_t stream);

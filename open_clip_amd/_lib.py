@@ -28,8 +28,8 @@ SIGNATURES = {
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_fwd_hd": [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd_hd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "ocn_attn_fwd_varlen": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "ocn_attn_bwd_varlen": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_fwd_varlen": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_bwd_varlen": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "ocn_patchify_u8": [_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _p, _i, _i, _i, _i, _i, _p],
     "ocn_embed_assemble_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -40,6 +40,7 @@ SIGNATURES = {
     "ocn_seq_pack_plan": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_seq_pack_rows": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_token_range_check": [_p, _l, _i, _p, _p],
+    "ocn_seq_bucket_plan": [_p, _p, _p, _i, _i, _p],
     "ocn_token_embed_fwd_rows": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ocn_token_embed_bwd_sorted_varlen": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],

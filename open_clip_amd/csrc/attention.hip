@@ -40,6 +40,11 @@ OCN_DEV SeqSpan seq_span(const int32_t* __restrict__ seq_off, int b, int Lmax) {
     return {(size_t)o, seq_off[b + 1] - o};
 }
 
+// Packed batches are launched in BUCKETS of equal block count (ocn_seq_pack_plan's `order`: sequence ids grouped by ceil(len / 32)):
+// a workgroup then has exactly as many waves and LDS rows as its sequence needs, instead of the longest sequence's -- these kernels
+// are latency-bound, their rate is the number of resident workgroups.  order == nullptr: workgroup i handles sequence i.
+OCN_DEV int seq_index(const int32_t* __restrict__ order, int order_off, int i) { return order ? order[order_off + i] : i; }
+
 // stage rows [0, LP) (clamped to L-1) of one head's 64-wide column block into LDS; all waves cooperate.  LP = the sequence's own
 // length rounded up to 32: a packed (varlen) batch never touches the 32-row blocks behind it.
 // NTL: non-temporal policy for the head's rows (read by this workgroup only) -- measured no faster than the default policy
@@ -118,13 +123,14 @@ OCN_DEV void flush_tile(const char* img, int row0, int lane, bf16* base, size_t 
 template <int MAXT, bool NTL>
 __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                          float* __restrict__ lse, const int32_t* __restrict__ seq_off, int Lmax, int H,
-                                                         int causal, float scale) {
+                                                         int causal, float scale, const int32_t* __restrict__ order, int order_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int LP = nwaves * 32;
-    const int b = blockIdx.x / H, hd = blockIdx.x % H;
+    const int hd = blockIdx.x % H;
+    const int b = seq_index(order, order_off, blockIdx.x / H);
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
     const SeqSpan sp = seq_span(seq_off, b, Lmax);  // dense: rows b*Lmax .. +Lmax; packed: rows seq_off[b] .. seq_off[b+1]
@@ -204,13 +210,14 @@ template <int MAXT, int WPE>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, int causal,
-                                                         float scale, int ablate) {
+                                                         float scale, int ablate, const int32_t* __restrict__ order, int order_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int LP = nwaves * 32;
-    const int b = blockIdx.x / H, hd = blockIdx.x % H;
+    const int hd = blockIdx.x % H;
+    const int b = seq_index(order, order_off, blockIdx.x / H);
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
     const SeqSpan sp = seq_span(seq_off, b, Lmax);
@@ -364,13 +371,15 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 template <int MAXT, int WPE>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_causal_kernel(
     const bf16* __restrict__ qkv, const bf16* __restrict__ out, const bf16* __restrict__ dout, const float* __restrict__ lse,
-    bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, float scale) {
+    bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, float scale, const int32_t* __restrict__ order,
+    int order_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int LP = nwaves * 32;
-    const int b = blockIdx.x / H, hd = blockIdx.x % H;
+    const int hd = blockIdx.x % H;
+    const int b = seq_index(order, order_off, blockIdx.x / H);
     const int C = H * 64;
     const size_t rs = (size_t)3 * C;
     const SeqSpan sp = seq_span(seq_off, b, Lmax);
@@ -500,33 +509,52 @@ int check_attn(const char* name, int B, int L, int H) {
 }  // namespace
 
 namespace {
-int attn_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* seq_off, int B, int L, int H, int causal, float scale,
-                  ocn_stream_t stream) {
-    OCN_CHECK_ARG(qkv && out && lse, "ocn_attn_fwd: null operand");
-    if (int e = check_attn("ocn_attn_fwd", B, L, H)) return e;
-    const int nw = ocn_cdiv(L, 32);
+// One launch of `nseq` sequences whose workgroups have `nw` waves (32 rows each).  Dense batches and un-bucketed packed batches: one
+// launch with nw = ceil(L / 32); bucketed packed batches: one launch per non-empty bucket (see seq_index).
+int attn_fwd_launch(const void* qkv, void* out, float* lse, const int32_t* seq_off, const int32_t* order, int order_off, int nseq, int nw,
+                    int L, int H, int causal, float scale, hipStream_t st) {
     const int lds = 3 * nw * 32 * 128;
     const bool ntl = g_ocn_tuning[9] == 2;
     if (nw <= 4) {
-        if (ntl) hipLaunchKernelGGL((attn_fwd_kernel<256, true>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale);
-        else hipLaunchKernelGGL((attn_fwd_kernel<256, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale);
+        if (ntl) hipLaunchKernelGGL((attn_fwd_kernel<256, true>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale, order, order_off);
+        else hipLaunchKernelGGL((attn_fwd_kernel<256, false>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale, order, order_off);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<640, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<640, false>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale);
+        hipLaunchKernelGGL((attn_fwd_kernel<640, false>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv, (bf16*)out, lse, seq_off, L, H, causal, scale, order, order_off);
     }
     OCN_CHECK_LAUNCH("ocn_attn_fwd");
     return OCN_OK;
 }
 
-int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off, int B, int L,
-                  int H, int causal, float scale, ocn_stream_t stream) {
-    OCN_CHECK_ARG(qkv && out && dout && lse && dqkv, "ocn_attn_bwd: null operand");
-    if (int e = check_attn("ocn_attn_bwd", B, L, H)) return e;
+int check_buckets(const char* fn, const int32_t* bucket_counts, int B, int L) {
+    long n = 0;
+    for (int k = 0; k < ocn_cdiv(L, 32); ++k) {
+        OCN_CHECK_ARG(bucket_counts[k] >= 0, "%s: negative bucket count", fn);
+        n += bucket_counts[k];
+    }
+    OCN_CHECK_ARG(n == B, "%s: bucket counts sum to %ld, not to B = %d", fn, n, B);
+    return OCN_OK;
+}
+
+int attn_fwd_impl(const void* qkv, void* out, float* lse, const int32_t* seq_off, const int32_t* order, const int32_t* bucket_counts, int B,
+                  int L, int H, int causal, float scale, ocn_stream_t stream) {
+    OCN_CHECK_ARG(qkv && out && lse, "ocn_attn_fwd: null operand");
+    if (int e = check_attn("ocn_attn_fwd", B, L, H)) return e;
     const int nw = ocn_cdiv(L, 32);
+    if (!order) return attn_fwd_launch(qkv, out, lse, seq_off, nullptr, 0, B, nw, L, H, causal, scale, (hipStream_t)stream);
+    if (int e = check_buckets("ocn_attn_fwd_varlen", bucket_counts, B, L)) return e;
+    for (int k = 1, off = 0; k <= nw; off += bucket_counts[k - 1], ++k)
+        if (bucket_counts[k - 1] > 0)
+            if (int e = attn_fwd_launch(qkv, out, lse, seq_off, order, off, bucket_counts[k - 1], k, L, H, causal, scale, (hipStream_t)stream)) return e;
+    return OCN_OK;
+}
+
+int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off,
+                    const int32_t* order, int order_off, int nseq, int nw, int L, int H, int causal, float scale, hipStream_t st) {
     int lds = 3 * nw * 32 * 128 + 2 * nw * 32 * 4;
     OCN_CHECK_ARG(lds <= 160 * 1024, "ocn_attn_bwd: L=%d needs %d bytes of LDS (> 160 KiB)", L, lds);
     if (g_ocn_tuning[5] > 0 && lds + g_ocn_tuning[5] * 1024 <= 160 * 1024) lds += g_ocn_tuning[5] * 1024;  // developer knob: lower the occupancy
@@ -537,8 +565,8 @@ int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const floa
             (void)hipFuncSetAttribute((const void*)attn_bwd_causal_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             cattr_set = true;
         }
-        hipLaunchKernelGGL((attn_bwd_causal_kernel<256, 2>), dim3(B * H), dim3(nw * 64), lds5, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, scale);
+        hipLaunchKernelGGL((attn_bwd_causal_kernel<256, 2>), dim3(nseq * H), dim3(nw * 64), lds5, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, scale, order, order_off);
         OCN_CHECK_LAUNCH("ocn_attn_bwd");
         return OCN_OK;
     }
@@ -549,51 +577,69 @@ int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const floa
             (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_bwd_kernel<256, 3>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1]);
+        hipLaunchKernelGGL((attn_bwd_kernel<256, 3>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
     } else if (nw <= 4) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_bwd_kernel<256, 2>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1]);
+        hipLaunchKernelGGL((attn_bwd_kernel<256, 2>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<640, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_bwd_kernel<640, 1>), dim3(B * H), dim3(nw * 64), lds, (hipStream_t)stream, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1]);
+        hipLaunchKernelGGL((attn_bwd_kernel<640, 1>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
     }
     OCN_CHECK_LAUNCH("ocn_attn_bwd");
+    return OCN_OK;
+}
+
+int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off,
+                  const int32_t* order, const int32_t* bucket_counts, int B, int L, int H, int causal, float scale, ocn_stream_t stream) {
+    OCN_CHECK_ARG(qkv && out && dout && lse && dqkv, "ocn_attn_bwd: null operand");
+    if (int e = check_attn("ocn_attn_bwd", B, L, H)) return e;
+    const int nw = ocn_cdiv(L, 32);
+    if (!order) return attn_bwd_launch(qkv, out, dout, lse, dqkv, seq_off, nullptr, 0, B, nw, L, H, causal, scale, (hipStream_t)stream);
+    if (int e = check_buckets("ocn_attn_bwd_varlen", bucket_counts, B, L)) return e;
+    for (int k = 1, off = 0; k <= nw; off += bucket_counts[k - 1], ++k)
+        if (bucket_counts[k - 1] > 0)
+            if (int e = attn_bwd_launch(qkv, out, dout, lse, dqkv, seq_off, order, off, bucket_counts[k - 1], k, L, H, causal, scale, (hipStream_t)stream)) return e;
     return OCN_OK;
 }
 }  // namespace
 
 extern "C" int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int causal, float scale, ocn_stream_t stream) {
-    return attn_fwd_impl(qkv, out, lse, nullptr, B, L, H, causal, scale, stream);
+    return attn_fwd_impl(qkv, out, lse, nullptr, nullptr, nullptr, B, L, H, causal, scale, stream);
 }
 
 extern "C" int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L, int H,
                             int causal, float scale, ocn_stream_t stream) {
-    return attn_bwd_impl(qkv, out, dout, lse, dqkv, nullptr, B, L, H, causal, scale, stream);
+    return attn_bwd_impl(qkv, out, dout, lse, dqkv, nullptr, nullptr, nullptr, B, L, H, causal, scale, stream);
 }
 
 // Packed ("varlen") batches, head_dim 64: sequence b owns rows seq_off[b] .. seq_off[b+1] of qkv / out / dout / dqkv
 // (1 <= length <= Lmax, seq_off = B + 1 ascending int32 on the device); lse keeps the dense [B, H, Lmax] layout.
-extern "C" int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* seq_off, int B, int Lmax, int H, int causal,
-                                   float scale, ocn_stream_t stream) {
+// Optional bucketing: `order` (device, B sequence ids grouped by ceil(len / 32) ascending, from ocn_seq_pack_plan) + `bucket_counts`
+// (HOST array of ceil(Lmax / 32) ints summing to B): one launch per non-empty bucket with workgroups sized for that bucket.
+extern "C" int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* seq_off, const int32_t* order,
+                                   const int32_t* bucket_counts, int B, int Lmax, int H, int causal, float scale, ocn_stream_t stream) {
     OCN_CHECK_ARG(seq_off, "ocn_attn_fwd_varlen: null seq_off");
-    return attn_fwd_impl(qkv, out, lse, seq_off, B, Lmax, H, causal, scale, stream);
+    OCN_CHECK_ARG((order == nullptr) == (bucket_counts == nullptr), "ocn_attn_fwd_varlen: order and bucket_counts go together");
+    return attn_fwd_impl(qkv, out, lse, seq_off, order, bucket_counts, B, Lmax, H, causal, scale, stream);
 }
 
 extern "C" int ocn_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off,
-                                   int B, int Lmax, int H, int causal, float scale, ocn_stream_t stream) {
+                                   const int32_t* order, const int32_t* bucket_counts, int B, int Lmax, int H, int causal, float scale,
+                                   ocn_stream_t stream) {
     OCN_CHECK_ARG(seq_off, "ocn_attn_bwd_varlen: null seq_off");
-    return attn_bwd_impl(qkv, out, dout, lse, dqkv, seq_off, B, Lmax, H, causal, scale, stream);
+    OCN_CHECK_ARG((order == nullptr) == (bucket_counts == nullptr), "ocn_attn_bwd_varlen: order and bucket_counts go together");
+    return attn_bwd_impl(qkv, out, dout, lse, dqkv, seq_off, order, bucket_counts, B, Lmax, H, causal, scale, stream);
 }
 
 // ---- explicit head_dim: dispatch between the specialised (head_dim 64, head resident) and the generic kernels ---------------

@@ -565,6 +565,36 @@ extern "C" int ocn_token_range_check(const int64_t* text, long n, int vocab, int
     return OCN_OK;
 }
 
+// Buckets of a packed batch for the attention launches (attention.hip::seq_index): order = the B sequence ids grouped by
+// nb = ceil(len / 32) ascending, counts[k] = how many sequences have nb == k + 1.  One workgroup; the position of a sequence INSIDE its
+// bucket comes from an LDS atomic (any order is correct: a workgroup's result does not depend on which workgroup computes it).
+__global__ __launch_bounds__(1024) void seq_bucket_kernel(const int32_t* __restrict__ seq_off, int32_t* __restrict__ order,
+                                                          int32_t* __restrict__ counts, int B, int nbuckets) {
+    __shared__ int cnt[16], cur[16];
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) atomicAdd(&cnt[(seq_off[b + 1] - seq_off[b] + 31) / 32 - 1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < nbuckets; ++k) {
+            counts[k] = cnt[k];
+            cur[k] = run;
+            run += cnt[k];
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 1024) order[atomicAdd(&cur[(seq_off[b + 1] - seq_off[b] + 31) / 32 - 1], 1)] = b;
+}
+
+extern "C" int ocn_seq_bucket_plan(const int32_t* seq_off, int32_t* order, int32_t* counts, int B, int Lmax, ocn_stream_t stream) {
+    OCN_CHECK_ARG(seq_off && order && counts && B > 0 && Lmax > 0, "ocn_seq_bucket_plan: bad arguments");
+    OCN_CHECK_ARG(Lmax <= 512, "ocn_seq_bucket_plan: Lmax = %d (at most 16 buckets of 32 rows)", Lmax);
+    hipLaunchKernelGGL(seq_bucket_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seq_off, order, counts, B, ocn_cdiv(Lmax, 32));
+    OCN_CHECK_LAUNCH("ocn_seq_bucket_plan");
+    return OCN_OK;
+}
+
 extern "C" int ocn_seq_pack_plan(const int64_t* text, int32_t* eot, int32_t* seq_off, int32_t* last_row, int B, int L, ocn_stream_t stream) {
     OCN_CHECK_ARG(text && eot && seq_off && last_row && B > 0 && L > 0, "ocn_seq_pack_plan: bad arguments");
     OCN_CHECK_ARG((long)B * L < 0x7fffffffL, "ocn_seq_pack_plan: B*L = %ld rows exceed int32 offsets", (long)B * L);

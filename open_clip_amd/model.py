@@ -158,6 +158,8 @@ def _side_stream(dev):
 # wait for the producing node: text-tower nodes (created last, run first in backward) sit on the caller's stream and wait for nothing,
 # the waits for the image tower's blocks queue up behind them.  The per-block wgrad side streams (_Paired) are switched off in this
 # mode (two MFMA-bound streams are enough; measured 191.5 with, 188.1 without).
+# OCN_ATTN_BUCKETS=0: packed text batches launch their attention kernels with every workgroup sized for context_length (A/B knob)
+_ATTN_BUCKETS = _os.environ.get("OCN_ATTN_BUCKETS", "1") != "0"
 _TOWER_STREAMS_DEFAULT = _os.environ.get("OCN_TOWER_STREAMS", "1") != "0"
 _TOWER_SIDE = {}
 
@@ -430,9 +432,9 @@ class _TextPack:
         self.vocab_size = vocab_size
         # with the vocabulary size the plan also counts ids outside [0, vocab): the embedding kernels clamp them (they can never read
         # outside the table), nn.Embedding raises (model.py:399) -- so does finish(), from the same 8-byte read-back
-        self.eot, plan, self.last_row = ops.seq_pack_plan(text, vocab_size)
-        self.seq_off = plan[:self.B + 1]
-        self._m_host = torch.empty(2 if vocab_size is not None else 1, dtype=torch.int32).pin_memory()
+        self.eot, plan, self.last_row, self.order = ops.seq_pack_plan(text, vocab_size, buckets=_ATTN_BUCKETS)
+        self.seq_off = self.layout = plan[:self.B + 1]
+        self._m_host = torch.empty(plan.numel() - self.B, dtype=torch.int32).pin_memory()  # [M, ids out of range, bucket counts ...]
         self._m_host.copy_(plan[self.B:], non_blocking=True)
         self._ready = torch.cuda.Event()
         self._ready.record()
@@ -445,6 +447,8 @@ class _TextPack:
                 raise IndexError(f"index out of range in self: {int(self._m_host[1])} token id(s) outside [0, {self.vocab_size}) "
                                  f"(token_embedding has {self.vocab_size} rows)")
             self.M = int(self._m_host[0])
+            if self.order is not None:  # attention launches in buckets of equal block count (ops.SeqLayout)
+                self.layout = ops.SeqLayout(self.seq_off, self.order, self._m_host[2:].tolist())
             self.tokens, self.posidx = ops.seq_pack_rows(self.text, self.seq_off, self.M)
         return self
 
@@ -831,7 +835,7 @@ class NativeCLIP(nn.Module):
             pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size)).finish()
             x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)
             yield
-            x = yield from self.transformer.steps(x, self._cache, B, L, True, pack.seq_off, pace, "follow")
+            x = yield from self.transformer.steps(x, self._cache, B, L, True, pack.layout, pace, "follow")
             # L = 0: last_row holds absolute rows of the packed matrix
             return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, pack.last_row, self._cache, B, 0, normalize)
         x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)

@@ -131,15 +131,41 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_b
 
 
 # ---- attention -------------------------------------------------------------------------------------------
+class SeqLayout:
+    """layout of a packed ("varlen") batch as the attention launches take it: ``seq_off`` (int32 [B+1], device) and, optionally, the
+    buckets of ocn_seq_bucket_plan -- ``order`` (int32 [B], device) + ``counts`` (host ints, one per 32-row block count)"""
+    __slots__ = ("seq_off", "order", "counts", "_c")
+
+    def __init__(self, seq_off, order=None, counts=None):
+        import ctypes
+        self.seq_off, self.order, self.counts = seq_off, order, (list(counts) if counts is not None else None)
+        self._c = (ctypes.c_int32 * len(self.counts))(*self.counts) if self.counts is not None else None
+
+    def args(self, B, L):
+        so = _chk(self.seq_off, torch.int32, "seq_off")
+        if self.order is None:
+            return so, 0, 0
+        if self.order.numel() != B or len(self.counts) != (L + 31) // 32 or sum(self.counts) != B:
+            raise RuntimeError(f"SeqLayout: order of {self.order.numel()} ids / counts {self.counts} do not describe B={B}, L={L}")
+        return so, _chk(self.order, torch.int32, "order"), self._c
+
+
+def _layout(seq_off):
+    return seq_off if isinstance(seq_off, SeqLayout) else SeqLayout(seq_off)
+
+
 def attn_fwd(qkv, B, L, H, causal, scale, head_dim=64, seq_off=None):
-    """``seq_off`` (int32 [B+1], device): packed batch -- sequence b owns rows seq_off[b]..seq_off[b+1] of qkv (head_dim 64 only)"""
+    """``seq_off`` (int32 [B+1] on the device, or a SeqLayout): packed batch -- sequence b owns rows seq_off[b]..seq_off[b+1] of qkv
+    (head_dim 64 only)"""
     C = H * head_dim
     if seq_off is not None:
-        if head_dim != 64 or qkv.shape[1] != 3 * C or seq_off.numel() != B + 1:
+        lay = _layout(seq_off)
+        if head_dim != 64 or qkv.shape[1] != 3 * C or lay.seq_off.numel() != B + 1:
             raise RuntimeError(f"attn_fwd(varlen): needs head_dim 64 and seq_off of B+1 entries (qkv {tuple(qkv.shape)}, head_dim {head_dim})")
         out = empty((qkv.shape[0], C), BF16, qkv)
         lse = empty((B * H * L,), F32, qkv)
-        _lib.call("ocn_attn_fwd_varlen", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), _chk(seq_off, torch.int32, "seq_off"),
+        so, order, counts = lay.args(B, L)
+        _lib.call("ocn_attn_fwd_varlen", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), so, order, counts,
                   B, L, H, int(causal), float(scale), _stream())
         return out, lse
     if qkv.shape != (B * L, 3 * C):
@@ -154,8 +180,9 @@ def attn_fwd(qkv, B, L, H, causal, scale, head_dim=64, seq_off=None):
 def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale, head_dim=64, seq_off=None):
     dqkv = empty(qkv.shape, BF16, qkv)
     if seq_off is not None:
+        so, order, counts = _layout(seq_off).args(B, L)
         _lib.call("ocn_attn_bwd_varlen", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
-                  _chk(dqkv, BF16, "dqkv"), _chk(seq_off, torch.int32, "seq_off"), B, L, H, int(causal), float(scale), _stream())
+                  _chk(dqkv, BF16, "dqkv"), so, order, counts, B, L, H, int(causal), float(scale), _stream())
         return dqkv
     delta = empty((B * H * L,), F32, qkv)  # workspace of the generic path (exchanged between its two launches)
     _lib.call("ocn_attn_bwd_hd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
@@ -230,17 +257,25 @@ def token_embed_bwd_sorted(text, dx, dtable, dpos):
               _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
 
 
-def seq_pack_plan(text, vocab=None):
-    """(eot [B], seq_off [B+1(+1)], last_row [B]) int32 on the device: the packed layout of a text batch (ocn_seq_pack_plan).  With
-    ``vocab`` the plan carries one more entry, seq_off[B+1] = the number of ids outside [0, vocab) (ocn_token_range_check)"""
+def seq_pack_plan(text, vocab=None, buckets=False):
+    """(eot [B], plan, last_row [B], order) int32 on the device: the packed layout of a text batch.  plan[0..B] = seq_off
+    (ocn_seq_pack_plan; plan[B] = the packed row count M), plan[B+1] = the number of ids outside [0, vocab) when ``vocab`` is given
+    (ocn_token_range_check), plan[B+2 ..] = the ceil(L / 32) bucket counts when ``buckets`` (ocn_seq_bucket_plan; ``order`` = the
+    sequence ids grouped by block count, else None)"""
     B, L = text.shape
-    n_off = B + 1 + (1 if vocab is not None else 0)
-    eot, seq_off, last_row = empty((B,), torch.int32, text), empty((n_off,), torch.int32, text), empty((B,), torch.int32, text)
-    _lib.call("ocn_seq_pack_plan", _chk(text, torch.int64, "text"), _chk(eot, torch.int32, "eot"), _chk(seq_off, torch.int32, "seq_off"),
+    nbk = (L + 31) // 32 if buckets else 0
+    eot, plan, last_row = empty((B,), torch.int32, text), empty((B + 2 + nbk,), torch.int32, text), empty((B,), torch.int32, text)
+    _lib.call("ocn_seq_pack_plan", _chk(text, torch.int64, "text"), _chk(eot, torch.int32, "eot"), _chk(plan, torch.int32, "seq_off"),
               _chk(last_row, torch.int32, "last_row"), B, L, _stream())
     if vocab is not None:
-        _lib.call("ocn_token_range_check", text.data_ptr(), B * L, int(vocab), seq_off.data_ptr() + 4 * (B + 1), _stream())
-    return eot, seq_off, last_row
+        _lib.call("ocn_token_range_check", text.data_ptr(), B * L, int(vocab), plan.data_ptr() + 4 * (B + 1), _stream())
+    else:
+        plan[B + 1:B + 2].zero_()
+    order = None
+    if buckets:
+        order = empty((B,), torch.int32, text)
+        _lib.call("ocn_seq_bucket_plan", plan.data_ptr(), _chk(order, torch.int32, "order"), plan.data_ptr() + 4 * (B + 2), B, L, _stream())
+    return eot, plan, last_row, order
 
 
 def token_range_check(text, vocab):

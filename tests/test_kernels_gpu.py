@@ -627,10 +627,17 @@ def test_seq_pack_plan_and_rows(dev, B, L):
     from open_clip_amd import ops
     g = torch.Generator().manual_seed(B + L)
     text = _random_text(B, L, 1000, g, full_every=5).to(dev)
-    eot, seq_off, last_row = ops.seq_pack_plan(text)
+    eot, plan, last_row, order = ops.seq_pack_plan(text, vocab=1000, buckets=True)
+    seq_off = plan[:B + 1]
     ref_eot = text.argmax(dim=-1)
     ref_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), (ref_eot + 1).cumsum(0)])
     assert torch.equal(eot.long(), ref_eot) and torch.equal(seq_off.long(), ref_off) and torch.equal(last_row.long(), ref_off[1:] - 1)
+    assert int(plan[B + 1]) == 0  # no id outside [0, vocab)
+    # buckets: counts per ceil(len / 32), order = a permutation of the sequences grouped by that key
+    nb = (ref_eot + 1 + 31) // 32
+    counts = plan[B + 2:].long()
+    assert counts.numel() == (L + 31) // 32 and torch.equal(counts, torch.bincount(nb - 1, minlength=counts.numel()))
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(B, device=dev)) and bool((nb[order.long()].diff() >= 0).all())
     M = int(seq_off[-1])
     tokens, posidx = ops.seq_pack_rows(text, seq_off, M)
     keep = torch.arange(L, device=dev)[None, :] <= ref_eot[:, None]
@@ -669,6 +676,14 @@ def test_attention_varlen(dev, B, L, H, causal):
     check(tag + " lse", torch.cat([t.reshape(-1) for t in got_lse]), torch.cat([t.reshape(-1) for t in ref_lse]), rel=1e-5)
     check(tag + " dqkv", dqkv, torch.cat(ref_d), rel=1.5e-2)
     assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all()
+    # the same batch launched in buckets of equal block count (workgroups sized for their own sequence): bit-identical results
+    nb = (lens + 31) // 32
+    order = torch.sort(nb, stable=True).indices.to(torch.int32).to(dev)
+    lay = ops.SeqLayout(seq_off, order, torch.bincount(nb - 1, minlength=(L + 31) // 32).tolist())
+    out_b, lse_b = ops.attn_fwd(qkv, B, L, H, causal, 0.125, seq_off=lay)
+    dqkv_b = ops.attn_bwd(qkv, out_b, dout, lse_b, B, L, H, causal, 0.125, seq_off=lay)
+    assert torch.equal(out_b, out) and torch.equal(dqkv_b, dqkv)
+    assert all(torch.equal(lse_b.reshape(B, H, L)[b, :, :int(lens[b])], lse.reshape(B, H, L)[b, :, :int(lens[b])]) for b in range(B))
 
 
 def test_attention_varlen_equals_dense_when_full(dev):
@@ -695,7 +710,8 @@ def test_token_embed_packed(dev, B, dx_dtype):
     text = _random_text(B, L, V, g).to(dev)
     table = torch.randn(V, C, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
     pos = torch.randn(L, C, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
-    eot, seq_off, last_row = ops.seq_pack_plan(text)
+    eot, plan, last_row, _ = ops.seq_pack_plan(text)
+    seq_off = plan[:B + 1]
     M = int(seq_off[-1])
     tokens, posidx = ops.seq_pack_rows(text, seq_off, M)
     x = ops.token_embed_fwd_rows(tokens, posidx, table, pos)

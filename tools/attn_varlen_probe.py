@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 B, L, H = 4096, 77, 8
 C = H * 64
 text = synthetic_batch(get_model_config("ViT-B-32"), B, seed=1234)["text"].to(dev)
-eot, seq_off, last = ops.seq_pack_plan(text)
+eot, plan, last, _ = ops.seq_pack_plan(text)
+seq_off = plan[:text.shape[0] + 1]
 M = int(seq_off[-1])
 
 

@@ -31,6 +31,11 @@ if has order; then  # how the two tower streams are fed: A/B/C in one process ea
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tower-order $ORD --force-ddp 2>&1 | grep '^{' >> $O/${TAG}_order_ddp_$ORD.json
   done; stamp order
 fi
+if has buckets; then  # packed text attention launched in buckets of equal block count vs every workgroup sized for context_length
+  for BK in 1 0 1 0; do
+    OCN_ATTN_BUCKETS=$BK timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_buckets_$BK.json
+  done; stamp buckets
+fi
 if has bench; then timeout 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
 if has lines; then
   timeout 300 python bench.py --steps 8 --warmup 2 --h2d $QUIET > $O/${TAG}_bench_h2d.log 2>&1
