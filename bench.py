@@ -67,8 +67,15 @@ def parse():
     return ap.parse_args()
 
 
+NT_KERNEL = {0: "gemm_nt5_kernel<0,false,0> (plain bf16 out)", 1: "gemm_nt5_kernel<1,false,2> (bias + GELU, saves gelu')",
+             2: "gemm_nt5_kernel<2,false,40> (bias + fp32 residual)", 3: "gemm_nt5_kernel<3,false,32> (x saved gelu')",
+             4: "gemm_nt5_kernel<4,false,0> (fp32 out)", 5: "gemm_nt5_kernel<5,false,0> (logits: CE statistics)",
+             6: "gemm_nt5_kernel<6,false,0> (logits: CE gradient)"}
+
+
 class GemmTimer:
-    """HIP events around every ocn_gemm_nt / ocn_gemm_tn_accum launch (same stream as the launch)."""
+    """HIP events around every ocn_gemm_nt / ocn_gemm_tn_accum launch (same stream as the launch), grouped by kernel instantiation
+    (the names rocprofv3 shows: the NT kernel's epilogue / cache-policy template arguments, the TN kernel with / without bias row)."""
 
     def __init__(self):
         self.rec = []
@@ -86,7 +93,8 @@ class GemmTimer:
             e0.record()
             r = nt(epi, a, b, out, **kw)
             e1.record()
-            timer.rec.append(("nt", 2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
+            name = "gemm_nt5_kernel<0,false,2> (wide bf16 out, non-temporal stores: QKV)" if (epi == 0 and b.shape[0] >= 1024) else NT_KERNEL.get(epi, f"gemm_nt epi {epi}")
+            timer.rec.append(("nt", name, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
             return r
 
         def gemm_tn(a, b, dw, dbias=None, alpha=1.0):
@@ -96,18 +104,21 @@ class GemmTimer:
             e0.record()
             r = tn(a, b, dw, dbias, alpha)
             e1.record()
-            timer.rec.append(("tn", 2.0 * a.shape[0] * a.shape[1] * b.shape[1], e0, e1))
+            name = "gemm_tn5_kernel<true> (wgrad + bias gradient)" if dbias is not None else "gemm_tn5_kernel<false> (wgrad)"
+            timer.rec.append(("tn", name, 2.0 * a.shape[0] * a.shape[1] * b.shape[1], e0, e1))
             return r
 
         ops.gemm_nt, ops.gemm_tn_accum = gemm_nt, gemm_tn
 
+    @staticmethod
+    def _agg(rows):
+        fl, ms, n = sum(r[2] for r in rows), sum(r[3].elapsed_time(r[4]) for r in rows), len(rows)
+        return {"launches": n, "tflop": fl / 1e12, "ms": ms, "tflops": (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0}
+
     def summary(self):
-        out = {}
-        for kind in ("nt", "tn"):
-            fl = sum(r[1] for r in self.rec if r[0] == kind)
-            ms = sum(r[2].elapsed_time(r[3]) for r in self.rec if r[0] == kind)
-            n = sum(1 for r in self.rec if r[0] == kind)
-            out[kind] = {"launches": n, "tflop": fl / 1e12, "ms": ms, "tflops": (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0}
+        out = {kind: self._agg([r for r in self.rec if r[0] == kind]) for kind in ("nt", "tn")}
+        out["all"] = self._agg(self.rec)
+        out["by_kernel"] = {name: self._agg([r for r in self.rec if r[1] == name]) for name in sorted({r[1] for r in self.rec})}
         return out
 
 
@@ -409,27 +420,48 @@ def main():
             line["dense_text_tower"] = dense_text
         if not args.no_roofline:
             s = timer.summary()
-            nt, tn = s["nt"], s["tn"]
-            traffic, traffic_src = None, None
+            nt, tn, allg = s["nt"], s["tn"], s["all"]
+            # the dominant kernel = the instantiation with the most time inside the event-timed steps (the same ranking as the rocprofv3
+            # summary under profiles/); the other GEMM kernels, the NT family and all GEMM launches together ride beside it
+            dom_name, dom = max(s["by_kernel"].items(), key=lambda kv: kv[1]["ms"])
+            step_ms_ev = elapsed * 1e3 * timed_steps / args.steps  # (approximate: event-timed steps are a little longer than the others)
+            traffic, traffic_src, traffic_by = None, None, {}
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_stats.py from the PMC passes
             if os.path.exists(tpath) and args.model == "ViT-B-32" and B == 4096:
                 rec = json.load(open(tpath))
-                traffic, traffic_src = round(rec["bytes_per_launch"]), rec["source"]
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt5_kernel (all epilogues)", "achieved": round(nt["tflops"], 1),
-                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(nt["tflops"] / PEAK_BF16_TFLOPS, 4),
-                                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "launches": nt["launches"], "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4),
-                                "algorithmic_tflop_per_launch_avg": round(nt["tflop"] / max(nt["launches"], 1), 4),
-                                "gemm_tn_kernel": {"achieved": round(tn["tflops"], 1), "frac": round(tn["tflops"] / PEAK_BF16_TFLOPS, 4),
-                                                   "launches": tn["launches"], "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4),
-                                                   "note": ("timed alone on the chip (event-timed steps run without the wgrad side stream)" if overlap_towers else
-                                                            "wgrad launches run on a side stream UNDER the LayerNorm / attention backward kernels of "
-                                                            "their block (model.py::_Paired), so these events time a co-scheduled kernel; alone it "
-                                                            "runs at ~1.1-1.2 PFLOP/s (bench.py without --serial-towers times it alone)")},
+                traffic_src = rec["source"]
+                traffic_by = rec.get("by_kernel", {})
+                key = dom_name.split(" ")[0]
+                traffic = round(traffic_by[key]["bytes_per_launch"]) if key in traffic_by else round(rec["bytes_per_launch"])
+
+            def krec(name, a):
+                r = {"kernel": name, "achieved": round(a["tflops"], 1), "frac": round(a["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": a["launches"],
+                     "avg_launch_ms": round(a["ms"] / max(a["launches"], 1), 4), "algorithmic_tflop_per_launch_avg": round(a["tflop"] / max(a["launches"], 1), 4),
+                     "share_of_gemm_time": round(a["ms"] / max(allg["ms"], 1e-9), 3)}
+                t = traffic_by.get(name.split(" ")[0])
+                if t:
+                    r["traffic"] = round(t["bytes_per_launch"])
+                return r
+
+            line["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(dom["tflops"], 1),
+                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
+                                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "launches": dom["launches"],
+                                "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                                "algorithmic_tflop_per_launch_avg": round(dom["tflop"] / max(dom["launches"], 1), 4),
+                                "dominant_by": "largest total time among the GEMM kernel instantiations inside the event-timed steps",
+                                "by_kernel": [krec(n, a) for n, a in sorted(s["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])],
+                                "gemm_nt_family": {"achieved": round(nt["tflops"], 1), "frac": round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": nt["launches"],
+                                                   "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
+                                "gemm_tn_family": {"achieved": round(tn["tflops"], 1), "frac": round(tn["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": tn["launches"],
+                                                   "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4)},
+                                "all_gemm_launches": {"achieved": round(allg["tflops"], 1), "frac": round(allg["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": allg["launches"]},
                                 "event_timed_steps": timed_steps,
                                 "event_timed_steps_mode": ("one tower at a time (same two streams, the image tower's held back behind the text tower's), no wgrad "
                                                            f"side stream: every GEMM launch alone on the chip; the other {args.steps - timed_steps} timed steps "
-                                                           "overlap the towers" if overlap_towers else "as every step"),
-                                "gemm_share_of_step": round((nt["ms"] + tn["ms"]) / (elapsed * 1e3 * timed_steps / args.steps), 3)}
+                                                           "overlap the towers" if overlap_towers else
+                                                           "as every step (wgrad launches run on a side stream under the LayerNorm / attention backward kernels of "
+                                                           "their block unless --no-wgrad-pair: their events then time a co-scheduled kernel)"),
+                                "gemm_share_of_step": round(allg["ms"] / step_ms_ev, 3)}
         if world == 1 and not args.no_eager_baseline and not args.siglip:
             micro.clear()
             torch.cuda.empty_cache()

@@ -49,6 +49,13 @@ def main():
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1`; "
                          "FETCH_SIZE doubled (gfx950 counts 128-byte requests at 64 B), KiB units"}
         rec["bytes_per_launch"] = rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]
+        # per kernel instantiation, keyed as bench.py names them ("gemm_nt5_kernel<2,false,40>", "gemm_tn5_kernel<true>")
+        rec["by_kernel"] = {}
+        for tot, n, rd, wr, us, k in rows:
+            if k.startswith("gemm_"):
+                key = k.split("(")[0].replace(", ", ",")
+                rec["by_kernel"][key] = {"launches": n, "read_bytes_per_launch": rd * 1e6, "write_bytes_per_launch": (wr if wr == wr else 0.0) * 1e6,
+                                         "bytes_per_launch": (rd + (wr if wr == wr else 0.0)) * 1e6}
         json.dump(rec, open(sys.argv[3], "w"), indent=1)
 
 
