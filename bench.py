@@ -108,7 +108,20 @@ class GemmTimer:
             timer.rec.append(("tn", name, 2.0 * a.shape[0] * a.shape[1] * b.shape[1], e0, e1))
             return r
 
-        ops.gemm_nt, ops.gemm_tn_accum = gemm_nt, gemm_tn
+        tn2 = ops.gemm_tn_accum2
+
+        def gemm_tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, alpha=1.0):
+            if not timer.on:
+                return tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, alpha)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, alpha)
+            e1.record()
+            name = "gemm_tn5_kernel<true> (wgrad + bias gradient)" if db1 is not None else "gemm_tn5_kernel<false> (wgrad)"
+            timer.rec.append(("tn", name, 2.0 * a1.shape[0] * (a1.shape[1] + a2.shape[1]) * b1.shape[1], e0, e1))
+            return r
+
+        ops.gemm_nt, ops.gemm_tn_accum, ops.gemm_tn_accum2 = gemm_nt, gemm_tn, gemm_tn2
 
     @staticmethod
     def _agg(rows):

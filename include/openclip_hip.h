@@ -59,6 +59,15 @@ int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, vo
 int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
                       float* dbias, float alpha, ocn_stream_t stream);
 
+/* Two weight gradients over the SAME M rows and the same K in ONE launch (both bias gradients or neither):
+ *   dW1[N1,K] += alpha * A1[M,N1]^T . B1[M,K],  dW2[N2,K] += alpha * A2[M,N2]^T . B2[M,K].
+ * The out-proj and QKV weight gradients of a residual block (autograd of transformer.py:169,246) are such a pair: alone, the small one
+ * needs 28-64 M-splits to fill the chip and spends 26-37 % of its time in contended atomics; paired they share 7 splits.  Shapes the
+ * paired kernel does not take are executed as two ocn_gemm_tn_accum calls (same results up to fp32 summation order). */
+int ocn_gemm_tn_accum2(const void* A1, int lda1, const void* B1, int ldb1, float* dW1, int ldw1, float* dbias1, int N1,
+                       const void* A2, int lda2, const void* B2, int ldb2, float* dW2, int ldw2, float* dbias2, int N2,
+                       int M, int K, float alpha, ocn_stream_t stream);
+
 /* The same with a caller-provided scratch buffer: when ocn_gemm_tn_workspace_bytes(M, N, K) > 0 (many M-splits accumulating into a
  * small dW: the out-proj / QKV weight gradients) and `workspace` holds that many bytes, every split stores its partial tile to its own
  * slab and a second kernel sums the slabs into dW, instead of 20..60-way contended fp32 atomics.  The query returns 0 (atomics) unless

@@ -27,7 +27,8 @@ int ocn_set_gemm_variant(int nt_variant);
  *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
  *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
  *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
- *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step) */
+ *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step)
+ *   key 13 1 = ocn_gemm_tn_accum2 never pairs (runs its two problems as two launches: A/B of the paired wgrad) */
 int ocn_set_tuning(int key, int value);
 /* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
  * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */

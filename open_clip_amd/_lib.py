@@ -17,6 +17,7 @@ _p, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 SIGNATURES = {
     "ocn_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p],
     "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
+    "ocn_gemm_tn_accum2": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p],
     "ocn_gemm_tn_accum_ws": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p, _l, _p],
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],

@@ -12,6 +12,8 @@
 // order (ocn_common.h xcd_remap).
 #include "gemm_args.h"
 
+extern int g_ocn_tuning[16];
+
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -499,6 +501,7 @@ extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int l
         if (rc < 0) ocn_set_error("ocn_gemm_tn_accum: launch failed");
         if (rc <= 0) return rc;
     }
+    a.A2 = a.B2 = nullptr; a.dW2 = a.dbias2 = nullptr; a.lda2 = a.ldb2 = a.ldw2 = a.N2 = a.ntile1 = a.ntile_all = 0;
     const int T = 128, RS = 64;  // the general kernel: 128x128 tile of dW, 64 reduction rows per step, M split to ~6 workgroups per CU
     a.tiles_n = ocn_cdiv(N, T);
     a.tiles_k = ocn_cdiv(K, T);
@@ -513,4 +516,28 @@ extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int l
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
     OCN_CHECK_LAUNCH("ocn_gemm_tn_accum");
     return OCN_OK;
+}
+
+// Two weight gradients over the SAME rows and the same K in one launch:  dW1[N1,K] += alpha * A1[M,N1]^T . B1[M,K]  and
+// dW2[N2,K] += alpha * A2[M,N2]^T . B2[M,K]  (+ their bias gradients, both or neither).  A block's out-proj and QKV wgrads are such a
+// pair (model.py::_BlockFn.backward): alone the 768 x 768 one needs 28 M-splits to fill the chip and spends a quarter of its time
+// in contended atomics.  Shapes the paired kernel does not take run as two ocn_gemm_tn_accum calls.
+extern "C" int ocn_gemm_tn_accum2(const void* A1, int lda1, const void* B1, int ldb1, float* dW1, int ldw1, float* dbias1, int N1,
+                                  const void* A2, int lda2, const void* B2, int ldb2, float* dW2, int ldw2, float* dbias2, int N2,
+                                  int M, int K, float alpha, ocn_stream_t stream) {
+    OCN_CHECK_ARG(A1 && B1 && dW1 && A2 && B2 && dW2, "ocn_gemm_tn_accum2: null operand");
+    OCN_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0 && K > 0, "ocn_gemm_tn_accum2: bad shape M=%d N1=%d N2=%d K=%d", M, N1, N2, K);
+    const bool big = (long)M * (N1 + N2) * K >= (1L << 31) && N1 >= 256 && N2 >= 256 && K >= 256;
+    const bool aligned = (((uintptr_t)A1 | (uintptr_t)B1 | (uintptr_t)A2 | (uintptr_t)B2) & 15) == 0;
+    if (big && aligned && (g_tn_variant == 0 || g_tn_variant == 3) && g_ocn_tuning[13] != 1) {  // developer knob 13 = 1: never pair
+        GemmTnArgs a;
+        a.A = (const bf16*)A1; a.B = (const bf16*)B1; a.dW = dW1; a.dbias = dbias1; a.lda = lda1; a.ldb = ldb1; a.ldw = ldw1; a.N = N1;
+        a.A2 = (const bf16*)A2; a.B2 = (const bf16*)B2; a.dW2 = dW2; a.dbias2 = dbias2; a.lda2 = lda2; a.ldb2 = ldb2; a.ldw2 = ldw2; a.N2 = N2;
+        a.M = M; a.K = K; a.alpha = alpha; a.ablate = 0; a.nsplit = 0; a.ws = nullptr;
+        const int rc = ocn_launch_tn5_pair(a, (hipStream_t)stream);
+        if (rc < 0) ocn_set_error("ocn_gemm_tn_accum2: launch failed");
+        if (rc <= 0) return rc;
+    }
+    if (int e = ocn_gemm_tn_accum(A1, lda1, B1, ldb1, dW1, ldw1, M, N1, K, dbias1, alpha, stream)) return e;
+    return ocn_gemm_tn_accum(A2, lda2, B2, ldb2, dW2, ldw2, M, N2, K, dbias2, alpha, stream);
 }

@@ -46,9 +46,18 @@ struct GemmTnArgs {
     int ablate;  // developer knob (ocn_set_tuning key 4): 1 = skip the atomic epilogue (timing only)
     float* ws;   // optional workspace [splits][N][K] (+ [splits][N] for dbias behind it): partial tiles instead of atomics (gemm_tn5.hip)
     int nsplit;
+    // optional SECOND problem of the same launch (gemm_tn5.hip, ocn_gemm_tn_accum2): dW2[N2,K] += alpha * A2[M,N2]^T . B2[M,K] over the
+    // same M rows and the same K; its tiles follow the first problem's in the tile index space (ntile1 = tiles of problem 1; 0 = none)
+    const bf16* A2;
+    const bf16* B2;
+    float* dW2;
+    float* dbias2;
+    int lda2, ldb2, ldw2, N2, ntile1, ntile_all;
 };
 
 // hand-scheduled 256x256 TN (wgrad) kernel (gemm_tn5.hip); returns 1 if the shape is not supported by it (caller falls back)
 int ocn_launch_tn5(GemmTnArgs a, hipStream_t st);
+// two wgrads over the same rows in ONE launch (a.A2 ... a.N2 set by the caller); returns 1 if the pair does not fit the kernel
+int ocn_launch_tn5_pair(GemmTnArgs a, hipStream_t st);
 // bytes of workspace with which ocn_launch_tn5 replaces its atomic epilogue by partial tiles + a reduce pass (0: atomics are fine)
 long ocn_tn5_workspace_bytes(int M, int N, int K);

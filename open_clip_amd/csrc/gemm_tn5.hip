@@ -60,8 +60,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wid = xcd_remap(blockIdx.x, a.nwg);
-    const int ntile = a.tiles_n * a.tiles_k;
-    const int split = wid / ntile, tile = wid % ntile;
+    const int ntile = a.ntile_all;
+    const int split = wid / ntile;
+    int tile = wid % ntile;
+    // Two problems in one launch (ocn_gemm_tn_accum2: the out-proj and QKV wgrads of a block share their rows and their K): a small dW
+    // alone needs 28-64 M-splits to fill the chip and then spends 26-37 % of its time in 28-64-way contended atomics
+    // (profiles/r01_tn5_epilogue_ablation.txt); together with its bigger sibling the pair has 36 tiles and 7 splits.
+    if (tile >= a.ntile1) {
+        tile -= a.ntile1;
+        a.A = a.A2; a.B = a.B2; a.dW = a.dW2; a.dbias = a.dbias2;
+        a.lda = a.lda2; a.ldb = a.ldb2; a.ldw = a.ldw2; a.N = a.N2;
+    }
     const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
     const int m_begin = split * a.chunk;
@@ -379,6 +388,8 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
         attr_set = true;
     }
     a.nsplit = splits;
+    a.ntile1 = a.ntile_all = ntile;  // single problem
+    a.A2 = a.B2 = nullptr; a.dW2 = a.dbias2 = nullptr; a.lda2 = a.ldb2 = a.ldw2 = a.N2 = 0;
     if (a.ws && (a.ldw % 4 || a.K % 4)) a.ws = nullptr;
     if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
     else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
@@ -388,6 +399,45 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(tn5_reduce_kernel, dim3(grid), dim3(256), 0, st, a.ws, a.dW, a.N, a.K, a.ldw, splits, a.alpha);
     }
+    if (hipGetLastError() != hipSuccess) return OCN_ERR_LAUNCH;
+    return OCN_OK;
+}
+
+int ocn_launch_tn5_pair(GemmTnArgs a, hipStream_t st) {
+    if (a.N % 8 || a.N2 % 8 || a.K % 8 || a.lda % 8 || a.ldb % 8 || a.lda2 % 8 || a.ldb2 % 8) return 1;
+    if ((a.dbias == nullptr) != (a.dbias2 == nullptr)) return 1;  // one kernel instantiation serves both problems
+    if (g_tn5_num_cu == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_tn5_num_cu = n;
+    }
+    a.ablate = g_ocn_tuning[4];
+    a.ws = nullptr;
+    a.tiles_k = ocn_cdiv(a.K, 256);
+    a.tiles_n = ocn_cdiv(a.N, 256);  // (problem 1; the kernel derives a tile's row from tiles_k only)
+    a.ntile1 = a.tiles_n * a.tiles_k;
+    a.ntile_all = a.ntile1 + ocn_cdiv(a.N2, 256) * a.tiles_k;
+    const int msteps = ocn_cdiv(a.M, 32);
+    int splits = g_tn5_num_cu / a.ntile_all;
+    if (splits < 1) splits = 1;
+    if (splits > msteps) splits = msteps;
+    a.chunk = ocn_cdiv(msteps, splits) * 32;
+    splits = ocn_cdiv(a.M, a.chunk);
+    a.nwg = splits * a.ntile_all;
+    a.nsplit = splits;
+    long ldmax = a.lda > a.ldb ? a.lda : a.ldb;
+    if (a.lda2 > ldmax) ldmax = a.lda2;
+    if (a.ldb2 > ldmax) ldmax = a.ldb2;
+    if ((long)(a.chunk + 128) * ldmax * 2 >= 0x7fffffffL) return 1;  // 32-bit buffer offsets (incl. the run-ahead past m_end)
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
     if (hipGetLastError() != hipSuccess) return OCN_ERR_LAUNCH;
     return OCN_OK;
 }

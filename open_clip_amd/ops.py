@@ -78,6 +78,26 @@ def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0):
     return dw
 
 
+def gemm_tn_accum2(a1, b1, dw1, dbias1, a2, b2, dw2, dbias2, alpha=1.0):
+    """two weight gradients over the same rows and the same K in ONE launch (ocn_gemm_tn_accum2):
+    dw1 += alpha * a1^T @ b1, dw2 += alpha * a2^T @ b2 (+ both bias gradients or neither)"""
+    M, K = b1.shape
+    if a1.shape[0] != M or a2.shape[0] != M or tuple(b2.shape) != (M, K) or tuple(dw1.shape) != (a1.shape[1], K) or tuple(dw2.shape) != (a2.shape[1], K):
+        raise RuntimeError(f"gemm_tn_accum2: shape mismatch a1{tuple(a1.shape)} b1{tuple(b1.shape)} dw1{tuple(dw1.shape)} "
+                           f"a2{tuple(a2.shape)} b2{tuple(b2.shape)} dw2{tuple(dw2.shape)}")
+    if (dbias1 is None) != (dbias2 is None):
+        raise RuntimeError("gemm_tn_accum2: both bias gradients or neither")
+    pa1, lda1 = _chk2d(a1, BF16, "a1")
+    pb1, ldb1 = _chk2d(b1, BF16, "b1")
+    pw1, ldw1 = _chk2d(dw1, F32, "dw1")
+    pa2, lda2 = _chk2d(a2, BF16, "a2")
+    pb2, ldb2 = _chk2d(b2, BF16, "b2")
+    pw2, ldw2 = _chk2d(dw2, F32, "dw2")
+    _lib.call("ocn_gemm_tn_accum2", pa1, lda1, pb1, ldb1, pw1, ldw1, _chk(dbias1, F32, "dbias1"), a1.shape[1],
+              pa2, lda2, pb2, ldb2, pw2, ldw2, _chk(dbias2, F32, "dbias2"), a2.shape[1], M, K, float(alpha), _stream())
+    return dw1, dw2
+
+
 # ---- casts --------------------------------------------------------------------------------------------
 def cast_bf16(src, out=None):
     out = empty(src.shape, BF16, src) if out is None else out

@@ -112,3 +112,37 @@ def test_gemm_tn_at_bench_shape(dev, name, M, N, K):
     e1, e2 = rel_l2(dw.double() - pre.double(), ref), rel_l2(db, refb)
     _report(f"bench-shape gemm_tn {name:18s} dW[{N}x{K}] over M={M}: rel_l2={e1:.3e} dbias rel_l2={e2:.3e}")
     assert torch.isfinite(dw).all() and e1 <= 2e-4 and e2 <= 2e-4, (name, e1, e2)
+
+
+@pytest.mark.parametrize("tag,M,C,bias", [("img", MI, 768, True), ("txt", MT, 512, True), ("txt packed", 177803, 512, True), ("img no bias", MI, 768, False),
+                                          ("small (two launches)", 3000, 128, True)])
+def test_gemm_tn_pair_at_bench_shape(dev, tag, M, C, bias):
+    """ocn_gemm_tn_accum2: the out-proj (dW[C,C]) and QKV (dW[3C,C]) weight gradients of a block in ONE launch, against fp32 torch in row
+    chunks and against the two single launches; both accumulate INTO pre-filled dW"""
+    from open_clip_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + C)
+    a1, b1 = bf(torch.randn(M, C, device=dev, generator=g)), bf(torch.randn(M, C, device=dev, generator=g))
+    a2, b2 = bf(torch.randn(M, 3 * C, device=dev, generator=g)), bf(torch.randn(M, C, device=dev, generator=g))
+    pre1, pre2 = torch.randn(C, C, device=dev, generator=g), torch.randn(3 * C, C, device=dev, generator=g)
+    dw1, dw2 = pre1.clone(), pre2.clone()
+    db1, db2 = (torch.zeros(C, device=dev), torch.zeros(3 * C, device=dev)) if bias else (None, None)
+    ops.gemm_tn_accum2(a1, b1, dw1, db1, a2, b2, dw2, db2)
+    s1, s2 = pre1.clone(), pre2.clone()
+    sb1, sb2 = (torch.zeros(C, device=dev), torch.zeros(3 * C, device=dev)) if bias else (None, None)
+    ops.gemm_tn_accum(a1, b1, s1, sb1)
+    ops.gemm_tn_accum(a2, b2, s2, sb2)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for a, b, dw, pre, db, single, sb in ((a1, b1, dw1, pre1, db1, s1, sb1), (a2, b2, dw2, pre2, db2, s2, sb2)):
+        ref = torch.zeros(dw.shape, device=dev, dtype=torch.float64)
+        refb = torch.zeros(dw.shape[0], device=dev, dtype=torch.float64)
+        for r0 in range(0, M, CHUNK):
+            sl = slice(r0, min(M, r0 + CHUNK))
+            ref += (a[sl].float().t() @ b[sl].float()).double()
+            refb += a[sl].float().sum(0).double()
+        e = [rel_l2(dw.double() - pre.double(), ref), rel_l2(dw.double() - pre.double(), single.double() - pre.double())]
+        if bias:
+            e += [rel_l2(db, refb), rel_l2(db, sb)]
+        assert torch.isfinite(dw).all() and max(e) <= 2e-4, (tag, dw.shape, e)
+        worst = max(worst, max(e))
+    _report(f"bench-shape paired wgrad {tag:12s} dW[{C}x{C}] + dW[{3 * C}x{C}] over M={M}: worst rel_l2 (vs fp32 torch, vs two single launches, dW and dbias) = {worst:.3e}")

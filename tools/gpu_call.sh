@@ -36,6 +36,12 @@ if has buckets; then  # packed text attention launched in buckets of equal block
     OCN_ATTN_BUCKETS=$BK timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_buckets_$BK.json
   done; stamp buckets
 fi
+if has tnpair; then  # out-proj + QKV wgrads in one launch vs two (developer knob 13)
+  timeout 300 python tools/ab_tn_pair.py > $O/${TAG}_tn_pair.txt 2>&1
+  for KN in 0 1 0 1; do
+    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tuning 13=$KN 2>&1 | grep '^{' >> $O/${TAG}_tnpair_$KN.json
+  done; stamp tnpair
+fi
 if has bench; then timeout 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
 if has lines; then
   timeout 300 python bench.py --steps 8 --warmup 2 --h2d $QUIET > $O/${TAG}_bench_h2d.log 2>&1
