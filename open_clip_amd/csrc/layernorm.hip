@@ -184,6 +184,134 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
+// The hot form of the backward (a residual block's two LayerNorms: dy bf16, fp32 residual gradient in, fp32 + bf16 dx out), software-
+// pipelined: the loads of a wave's NEXT row (x, dres, dy, mean, rstd: 10 bytes per element) are issued before the arithmetic, the two
+// wave reductions and the stores of the current one.  A row is one memory round trip; with one row per wave in flight the kernel
+// holds (waves per CU) x 10 C bytes in flight and runs at 4.2 (C = 512) - 4.9 (C = 768) TB/s, with two rows ~30 more VGPRs buy twice
+// that per wave.  Same arithmetic and order of operations as ln_bwd_kernel (up to where the compiler contracts a multiply-add).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dres, float* __restrict__ dx32, bf16* __restrict__ dx16,
+                                                         float* __restrict__ dw, float* __restrict__ db, int M, int C) {
+    __shared__ float red[3][NV * 256 * 2];  // waves 1..3 -> wave 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invC = 1.0f / (float)C;
+    f32x4 aw[NV], ab[NV], wv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        aw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ab[i] = aw[i];
+        wv[i] = (c < C) ? *(const f32x4*)(w + c) : aw[i];
+    }
+    struct RowIn {
+        f32x4 x[NV], dr[NV];
+        uint2 dy[NV];  // four bf16, kept raw until they are used
+        float mu, rs;
+    };
+    auto load = [&](int row, RowIn& r) {
+        r.mu = mean[row];
+        r.rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                r.dr[i] = __builtin_nontemporal_load((const f32x4*)(dres + (size_t)row * C + c));
+                r.x[i] = __builtin_nontemporal_load((const f32x4*)(x + (size_t)row * C + c));
+                r.dy[i] = *(const uint2*)(dy + (size_t)row * C + c);
+            }
+        }
+    };
+    auto process = [&](int row, const RowIn& r) {
+        f32x4 xh[NV], g[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            g[i] = xh[i];
+            if (c < C) {
+                // bf16 -> fp32 is a 16-bit shift
+                const f32x4 d = {__uint_as_float(r.dy[i].x << 16), __uint_as_float(r.dy[i].x & 0xffff0000u), __uint_as_float(r.dy[i].y << 16),
+                                 __uint_as_float(r.dy[i].y & 0xffff0000u)};
+                // whole-vector arithmetic (element-wise updates of the captured accumulators end up in scratch memory); per element the
+                // operations and their order are those of ln_bwd_kernel
+                xh[i] = (r.x[i] - r.mu) * r.rs;
+                g[i] = d * wv[i];
+                const f32x4 gx = g[i] * xh[i];
+                c1 += g[i][0];
+                c2 += gx[0];
+                c1 += g[i][1];
+                c2 += gx[1];
+                c1 += g[i][2];
+                c2 += gx[2];
+                c1 += g[i][3];
+                c2 += gx[3];
+                aw[i] = aw[i] + d * xh[i];
+                ab[i] = ab[i] + d;
+            }
+        }
+        c1 = wave_sum(c1) * invC;
+        c2 = wave_sum(c2) * invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                f32x4 o = (g[i] - c1 - xh[i] * c2) * r.rs;
+                o = o + r.dr[i];
+                __builtin_nontemporal_store(o, (f32x4*)(dx32 + (size_t)row * C + c));
+                const bf16x4 o4 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                *(bf16x4*)(dx16 + (size_t)row * C + c) = o4;
+            }
+        }
+    };
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    RowIn ra, rb;
+    if (row < M) load(row, ra);
+    while (row < M) {  // ping-pong between the two register sets: no copies
+        int nrow = row + stride;
+        if (nrow < M) load(nrow, rb);
+        process(row, ra);
+        row = nrow;
+        if (row >= M) break;
+        nrow = row + stride;
+        if (nrow < M) load(nrow, ra);
+        process(row, rb);
+        row = nrow;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[wave - 1][((i * 4 + e) * 64 + lane) * 2] = aw[i][e];
+                red[wave - 1][((i * 4 + e) * 64 + lane) * 2 + 1] = ab[i][e];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sw = aw[i][e], sb = ab[i][e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sw += red[k][((i * 4 + e) * 64 + lane) * 2];
+                    sb += red[k][((i * 4 + e) * 64 + lane) * 2 + 1];
+                }
+                if (c < C) {
+                    unsafeAtomicAdd(dw + c + e, sw);
+                    unsafeAtomicAdd(db + c + e, sb);
+                }
+            }
+        }
+    }
+}
+
 int ln_grid(int M) {
     int g = ocn_cdiv(M, 4);
     return g < 2048 ? g : 2048;
@@ -199,6 +327,11 @@ void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, c
                 const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C,
                 const bf16* dres_hi, const bf16* dres_lo, bf16* dx_lo) {
     const bool nt = g_ocn_tuning[8] != 1;  // developer knob 8 = 1: default cache policy everywhere
+    // the residual blocks' form goes to the software-pipelined kernel (developer knob 8 = 2: one row per wave in flight, as before)
+    if (!dy_is_f32 && dres && dx32 && dx16 && !dres_hi && !dx_lo && NV <= 3 && g_ocn_tuning[8] == 0) {  // (C <= 768: beyond, the second row's registers cost more occupancy than they buy)
+        ln_bwd_pf_kernel<NV><<<dim3(ln_grid(M)), dim3(256), 0, st>>>((const bf16*)dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+        return;
+    }
     if (dy_is_f32) {
         if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
         else ln_bwd_kernel<NV, true, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
