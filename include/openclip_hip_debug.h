@@ -24,11 +24,12 @@ int ocn_set_gemm_variant(int nt_variant);
  *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)
  *   key 2  attention backward: 3 = the 168-VGPR build (3 waves per SIMD)      key 4  wgrad GEMM: 1 = skip the atomic epilogue
  *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
- *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  LayerNorm backward: 1 = default cache policy, 2 = one row per wave in flight (no software pipelining)
+ *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
  *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
  *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
  *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step)
- *   key 13 1 = ocn_gemm_tn_accum2 never pairs (runs its two problems as two launches: A/B of the paired wgrad) */
+ *   key 13 1 = ocn_gemm_tn_accum2 never pairs (runs its two problems as two launches: A/B of the paired wgrad)
+ *   key 14 n = workgroups of the LayerNorm backward's grid (default: one 16-wave workgroup per CU) */
 int ocn_set_tuning(int key, int value);
 /* developer probe: n workgroups that each hold (most of) a CU's LDS for `micros` microseconds on `stream` -- a stand-in for
  * collective kernels occupying CUs while a persistent GEMM starts (tools/occupancy_hazard_probe.py) */

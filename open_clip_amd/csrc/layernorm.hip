@@ -1,7 +1,7 @@
 // LayerNorm forward / backward over the last dimension (HBM-bound; fp32 statistics).
 // One wave per row, 16-byte vector accesses, rows grid-strided; the backward keeps per-lane partial sums
-// of dgamma/dbeta in registers across its rows, folds the 4 waves of a workgroup through LDS and issues one
-// fp32 atomic per column per workgroup.
+// of dgamma/dbeta in registers across its rows, folds the 16 waves of a workgroup (one workgroup per CU) through LDS and issues
+// one fp32 atomic per column per workgroup.
 // Algorithmic bytes per row of C columns: fwd 4C (x fp32) + 2C (y bf16) [+4C if y fp32];
 // bwd 2C|4C (dy) + 4C (x) [+4C dres] + 4C (dx fp32) + 2C (dx bf16).
 #include "ocn_common.h"
@@ -67,15 +67,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // NT: x and the residual gradient (read once, long after they were written) are loaded and the fp32 dx (read again only by the
 // next LayerNorm backward, two GEMMs later) is stored with the non-temporal policy; dy and the bf16 dx, which the neighbouring
 // GEMMs produce / consume right away, keep the default one.
+// Workgroups of BW = 16 waves, ONE per CU (C <= 768; wider rows keep 4-wave workgroups: their registers allow fewer waves), rows grid-strided: the dgamma / dbeta partials of a workgroup's waves
+// are folded through LDS (a tree, BW / 2 slabs) and leave as one fp32 atomic per column per WORKGROUP -- with 2048 four-wave workgroups
+// the 2048-way contended atomics were 0.06-0.17 ms of a 0.37-0.52 ms launch (profiles/r02_layernorm_grid.txt).
+template <int NV>
+constexpr int ln_bwd_waves() { return NV <= 3 ? 16 : 4; }
+
 template <int NV, bool DY32, bool NT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dyv, const float* __restrict__ x,
+__global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const void* __restrict__ dyv, const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
                                                       float* __restrict__ dx32, bf16* __restrict__ dx16,
                                                       float* __restrict__ dw, float* __restrict__ db, int M, int C,
                                                       const bf16* __restrict__ dres_hi, const bf16* __restrict__ dres_lo,
                                                       bf16* __restrict__ dx_lo) {
-    __shared__ float red[3][NV * 256 * 2];  // waves 1..3 -> wave 0
+    constexpr int BW = ln_bwd_waves<NV>();
+    __shared__ float red[BW / 2][NV * 256 * 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invC = 1.0f / (float)C;
     f32x4 aw[NV], ab[NV], wv[NV];
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         ab[i] = aw[i];
         wv[i] = (c < C) ? *(const f32x4*)(w + c) : aw[i];
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * BW + wave; row < M; row += gridDim.x * BW) {
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NV], g[NV], dr[NV];
         float c1 = 0.f, c2 = 0.f;
@@ -152,160 +159,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             }
         }
     }
-    // fold the 4 waves, then one atomic per column per workgroup
-    if (wave > 0) {
+    // fold the BW waves pairwise through LDS (upper half writes, lower half adds), then one atomic per column per workgroup
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
+    for (int half = BW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                red[wave - 1][((i * 4 + e) * 64 + lane) * 2] = aw[i][e];
-                red[wave - 1][((i * 4 + e) * 64 + lane) * 2 + 1] = ab[i][e];
-            }
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    red[wave - half][((i * 4 + e) * 64 + lane) * 2] = aw[i][e];
+                    red[wave - half][((i * 4 + e) * 64 + lane) * 2 + 1] = ab[i][e];
+                }
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    aw[i][e] += red[wave][((i * 4 + e) * 64 + lane) * 2];
+                    ab[i][e] += red[wave][((i * 4 + e) * 64 + lane) * 2 + 1];
+                }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float sw = aw[i][e], sb = ab[i][e];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    sw += red[k][((i * 4 + e) * 64 + lane) * 2];
-                    sb += red[k][((i * 4 + e) * 64 + lane) * 2 + 1];
-                }
                 if (c < C) {
-                    unsafeAtomicAdd(dw + c + e, sw);
-                    unsafeAtomicAdd(db + c + e, sb);
-                }
-            }
-        }
-    }
-}
-
-// The hot form of the backward (a residual block's two LayerNorms: dy bf16, fp32 residual gradient in, fp32 + bf16 dx out), software-
-// pipelined: the loads of a wave's NEXT row (x, dres, dy, mean, rstd: 10 bytes per element) are issued before the arithmetic, the two
-// wave reductions and the stores of the current one.  A row is one memory round trip; with one row per wave in flight the kernel
-// holds (waves per CU) x 10 C bytes in flight and runs at 4.2 (C = 512) - 4.9 (C = 768) TB/s, with two rows ~30 more VGPRs buy twice
-// that per wave.  Same arithmetic and order of operations as ln_bwd_kernel (up to where the compiler contracts a multiply-add).
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ dres, float* __restrict__ dx32, bf16* __restrict__ dx16,
-                                                         float* __restrict__ dw, float* __restrict__ db, int M, int C) {
-    __shared__ float red[3][NV * 256 * 2];  // waves 1..3 -> wave 0
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float invC = 1.0f / (float)C;
-    f32x4 aw[NV], ab[NV], wv[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        aw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        ab[i] = aw[i];
-        wv[i] = (c < C) ? *(const f32x4*)(w + c) : aw[i];
-    }
-    struct RowIn {
-        f32x4 x[NV], dr[NV];
-        uint2 dy[NV];  // four bf16, kept raw until they are used
-        float mu, rs;
-    };
-    auto load = [&](int row, RowIn& r) {
-        r.mu = mean[row];
-        r.rs = rstd[row];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < C) {
-                r.dr[i] = __builtin_nontemporal_load((const f32x4*)(dres + (size_t)row * C + c));
-                r.x[i] = __builtin_nontemporal_load((const f32x4*)(x + (size_t)row * C + c));
-                r.dy[i] = *(const uint2*)(dy + (size_t)row * C + c);
-            }
-        }
-    };
-    auto process = [&](int row, const RowIn& r) {
-        f32x4 xh[NV], g[NV];
-        float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            g[i] = xh[i];
-            if (c < C) {
-                // bf16 -> fp32 is a 16-bit shift
-                const f32x4 d = {__uint_as_float(r.dy[i].x << 16), __uint_as_float(r.dy[i].x & 0xffff0000u), __uint_as_float(r.dy[i].y << 16),
-                                 __uint_as_float(r.dy[i].y & 0xffff0000u)};
-                // whole-vector arithmetic (element-wise updates of the captured accumulators end up in scratch memory); per element the
-                // operations and their order are those of ln_bwd_kernel
-                xh[i] = (r.x[i] - r.mu) * r.rs;
-                g[i] = d * wv[i];
-                const f32x4 gx = g[i] * xh[i];
-                c1 += g[i][0];
-                c2 += gx[0];
-                c1 += g[i][1];
-                c2 += gx[1];
-                c1 += g[i][2];
-                c2 += gx[2];
-                c1 += g[i][3];
-                c2 += gx[3];
-                aw[i] = aw[i] + d * xh[i];
-                ab[i] = ab[i] + d;
-            }
-        }
-        c1 = wave_sum(c1) * invC;
-        c2 = wave_sum(c2) * invC;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < C) {
-                f32x4 o = (g[i] - c1 - xh[i] * c2) * r.rs;
-                o = o + r.dr[i];
-                __builtin_nontemporal_store(o, (f32x4*)(dx32 + (size_t)row * C + c));
-                const bf16x4 o4 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-                *(bf16x4*)(dx16 + (size_t)row * C + c) = o4;
-            }
-        }
-    };
-    const int stride = gridDim.x * 4;
-    int row = blockIdx.x * 4 + wave;
-    RowIn ra, rb;
-    if (row < M) load(row, ra);
-    while (row < M) {  // ping-pong between the two register sets: no copies
-        int nrow = row + stride;
-        if (nrow < M) load(nrow, rb);
-        process(row, ra);
-        row = nrow;
-        if (row >= M) break;
-        nrow = row + stride;
-        if (nrow < M) load(nrow, ra);
-        process(row, rb);
-        row = nrow;
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                red[wave - 1][((i * 4 + e) * 64 + lane) * 2] = aw[i][e];
-                red[wave - 1][((i * 4 + e) * 64 + lane) * 2 + 1] = ab[i][e];
-            }
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float sw = aw[i][e], sb = ab[i][e];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    sw += red[k][((i * 4 + e) * 64 + lane) * 2];
-                    sb += red[k][((i * 4 + e) * 64 + lane) * 2 + 1];
-                }
-                if (c < C) {
-                    unsafeAtomicAdd(dw + c + e, sw);
-                    unsafeAtomicAdd(db + c + e, sb);
+                    unsafeAtomicAdd(dw + c + e, aw[i][e]);
+                    unsafeAtomicAdd(db + c + e, ab[i][e]);
                 }
             }
         }
@@ -315,6 +201,20 @@ __global__ __launch_bounds__(256) void ln_bwd_pf_kernel(const bf16* __restrict__
 int ln_grid(int M) {
     int g = ocn_cdiv(M, 4);
     return g < 2048 ? g : 2048;
+}
+int g_ln_num_cu = 0;
+template <int NV>
+int ln_bwd_grid(int M) {
+    if (g_ln_num_cu == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_ln_num_cu = n;
+    }
+    const int g = ocn_cdiv(M, ln_bwd_waves<NV>());
+    // developer knob 14: workgroups of the backward's grid
+    const int cap = g_ocn_tuning[14] > 0 ? g_ocn_tuning[14] : (ln_bwd_waves<NV>() == 16 ? g_ln_num_cu : 2048);
+    return g < cap ? g : cap;
 }
 
 template <int NV>
@@ -327,17 +227,12 @@ void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, c
                 const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C,
                 const bf16* dres_hi, const bf16* dres_lo, bf16* dx_lo) {
     const bool nt = g_ocn_tuning[8] != 1;  // developer knob 8 = 1: default cache policy everywhere
-    // the residual blocks' form goes to the software-pipelined kernel (developer knob 8 = 2: one row per wave in flight, as before)
-    if (!dy_is_f32 && dres && dx32 && dx16 && !dres_hi && !dx_lo && NV <= 3 && g_ocn_tuning[8] == 0) {  // (C <= 768: beyond, the second row's registers cost more occupancy than they buy)
-        ln_bwd_pf_kernel<NV><<<dim3(ln_grid(M)), dim3(256), 0, st>>>((const bf16*)dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
-        return;
-    }
     if (dy_is_f32) {
-        if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
-        else ln_bwd_kernel<NV, true, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
+        if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
+        else ln_bwd_kernel<NV, true, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
     } else {
-        if (nt) ln_bwd_kernel<NV, false, true><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
-        else ln_bwd_kernel<NV, false, false><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
+        if (nt) ln_bwd_kernel<NV, false, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
+        else ln_bwd_kernel<NV, false, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
     }
 }
 

@@ -42,11 +42,8 @@ if has tnpair; then  # out-proj + QKV wgrads in one launch vs two (developer kno
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tuning 13=$KN 2>&1 | grep '^{' >> $O/${TAG}_tnpair_$KN.json
   done; stamp tnpair
 fi
-if has lnpf; then  # software-pipelined LayerNorm backward vs one row per wave (developer knob 8 = 2)
-  timeout 300 python tools/ab_ln_bwd.py > $O/${TAG}_ln_bwd.txt 2>&1
-  for KN in 0 2 0 2; do
-    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tuning 8=$KN 2>&1 | grep '^{' >> $O/${TAG}_lnpf_$KN.json
-  done; stamp lnpf
+if has lngrid; then  # LayerNorm backward: 16-wave workgroups, one per CU (default) against other grid sizes
+  timeout 300 python tools/ab_ln_bwd.py 0,128,256,512,1024 > $O/${TAG}_ln_grid.txt 2>&1; stamp lngrid
 fi
 if has bench; then timeout 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
 if has lines; then
