@@ -67,11 +67,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // NT: x and the residual gradient (read once, long after they were written) are loaded and the fp32 dx (read again only by the
 // next LayerNorm backward, two GEMMs later) is stored with the non-temporal policy; dy and the bf16 dx, which the neighbouring
 // GEMMs produce / consume right away, keep the default one.
-// Workgroups of BW = 16 waves, ONE per CU (C <= 768; wider rows keep 4-wave workgroups: their registers allow fewer waves), rows grid-strided: the dgamma / dbeta partials of a workgroup's waves
+// Workgroups of BW = 16 waves (12 for C <= 1280, 8 beyond: registers), ONE per CU, rows grid-strided: the dgamma / dbeta partials of a workgroup's waves
 // are folded through LDS (a tree, BW / 2 slabs) and leave as one fp32 atomic per column per WORKGROUP -- with 2048 four-wave workgroups
 // the 2048-way contended atomics were 0.06-0.17 ms of a 0.37-0.52 ms launch (profiles/r02_layernorm_grid.txt).
 template <int NV>
-constexpr int ln_bwd_waves() { return NV <= 3 ? 16 : 4; }
+constexpr int ln_bwd_waves() { return NV <= 3 ? 16 : (NV <= 5 ? 12 : 8); }  // what the registers of a row's NV x 16 bytes per lane leave room for
 
 template <int NV, bool DY32, bool NT>
 __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const void* __restrict__ dyv, const float* __restrict__ x,
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                                                       const bf16* __restrict__ dres_hi, const bf16* __restrict__ dres_lo,
                                                       bf16* __restrict__ dx_lo) {
     constexpr int BW = ln_bwd_waves<NV>();
-    __shared__ float red[BW / 2][NV * 256 * 2];
+    __shared__ float red[(BW + 1) / 2][NV * 256 * 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invC = 1.0f / (float)C;
     f32x4 aw[NV], ab[NV], wv[NV];
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
     }
     // fold the BW waves pairwise through LDS (upper half writes, lower half adds), then one atomic per column per workgroup
 #pragma unroll
-    for (int half = BW / 2; half >= 1; half >>= 1) {
-        if (wave >= half && wave < 2 * half) {
+    for (int n = BW; n > 1; n = (n + 1) / 2) {  // n live partials -> ceil(n / 2)
+        const int half = (n + 1) / 2;
+        if (wave >= half && wave < n) {
 #pragma unroll
             for (int i = 0; i < NV; ++i)
 #pragma unroll
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                 }
         }
         __syncthreads();
-        if (wave < half) {
+        if (wave < n - half) {
 #pragma unroll
             for (int i = 0; i < NV; ++i)
 #pragma unroll
@@ -213,7 +214,7 @@ int ln_bwd_grid(int M) {
     }
     const int g = ocn_cdiv(M, ln_bwd_waves<NV>());
     // developer knob 14: workgroups of the backward's grid
-    const int cap = g_ocn_tuning[14] > 0 ? g_ocn_tuning[14] : (ln_bwd_waves<NV>() == 16 ? g_ln_num_cu : 2048);
+    const int cap = g_ocn_tuning[14] > 0 ? g_ocn_tuning[14] : g_ln_num_cu;
     return g < cap ? g : cap;
 }
 
