@@ -340,15 +340,15 @@ def test_training_steps_with_fused_optimizer_track_the_cpu_oracle():
         # Adam turns a gradient into a step of ~lr per element whatever its size, so elements whose gradient is (nearly) rounding
         # noise -- the K third of in_proj_bias (softmax is invariant to it: exact gradient zero), embedding rows of rare tokens --
         # move differently in any two implementations; the bound only has to catch a wrong update (error ~ the movement itself)
-        bound = 0.35
+        bound = 0.20  # measured worst: 0.11 (token_embedding.weight: rows of rare tokens)
         assert float(err) <= bound * float(moved) + 1e-6, (k, float(err), float(moved))
         ratio = float(err) / (float(moved) + 1e-30)
         worst_any = max(worst_any, (ratio, k))
         if ref.dim() >= 2 and ref.numel() >= 4096 and "embedding" not in k:
             worst_mat = max(worst_mat, (ratio, k))
     _report(f"train-steps: error / movement of the parameters after the steps: worst {worst_any[0]:.3f} ({worst_any[1]}), worst weight matrix {worst_mat[0]:.3f} "
-            f"({worst_mat[1]}); bounds 0.35 / 0.20")
-    assert worst_mat[0] <= 0.20, worst_mat  # weight matrices (every element has a real gradient): a tighter bound than the noisy 1-D tensors
+            f"({worst_mat[1]}); bounds 0.20 / 0.10")
+    assert worst_mat[0] <= 0.10, worst_mat  # weight matrices (every element has a real gradient; measured worst 0.051): tighter than the noisy 1-D tensors
 
 
 def test_reference_train_loop_under_autocast_tracks_the_cpu_oracle():
@@ -411,13 +411,17 @@ def test_reference_train_loop_under_autocast_tracks_the_cpu_oracle():
         _report(f"autocast-loop[{i}]: loss {float(total_loss.detach()):.5f} oracle {float(outs['loss']):.5f}")
         assert abs(float(total_loss.detach()) - float(outs["loss"])) <= LOSS_TOL, i
     torch.cuda.synchronize()
+    worst = (0.0, "")
     for k, p in model.named_parameters():
         ref, got, start = ref_params[k].detach(), p.detach().float().cpu(), state[k].float()
         if k.endswith("attn.in_proj_bias"):  # the K third has an exactly-zero gradient: Adam moves it by rounding noise alone
             c = ref.numel() // 3
             keep = torch.cat([torch.arange(0, c), torch.arange(2 * c, 3 * c)])
             ref, got, start = ref[keep], got[keep], start[keep]
-        assert float((got - ref).norm()) <= 0.35 * float((ref - start).norm()) + 1e-6, k
+        ratio = float((got - ref).norm()) / (float((ref - start).norm()) + 1e-30)
+        worst = max(worst, (ratio, k))
+        assert ratio <= 0.25 + 1e-6, (k, ratio)
+    _report(f"autocast-loop: error / movement of the parameters after the steps: worst {worst[0]:.3f} ({worst[1]}); bound 0.25")
 
 
 def test_vith14_siglip_full_size_against_cpu_oracle_and_loss_after_one_update():
