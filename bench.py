@@ -93,7 +93,7 @@ class GemmTimer:
             e0.record()
             r = nt(epi, a, b, out, **kw)
             e1.record()
-            name = "gemm_nt5_kernel<0,false,2> (wide bf16 out, non-temporal stores: QKV)" if (epi == 0 and b.shape[0] >= 1024) else NT_KERNEL.get(epi, f"gemm_nt epi {epi}")
+            name = "gemm_nt5_kernel<0,false,2> (bf16 out with N >= 1024, non-temporal stores: the QKV projections of ViT-B-32)" if (epi == 0 and b.shape[0] >= 1024) else NT_KERNEL.get(epi, f"gemm_nt epi {epi}")
             timer.rec.append(("nt", name, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
             return r
 
