@@ -51,8 +51,6 @@ def parse():
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--serial-towers", action="store_true", help="image and text tower on ONE stream (default: the image tower on a stream of its own next "
                     "to the text tower, model.py::_TOWER_SIDE; the steps whose GEMM launches carry HIP events always run serially)")
-    ap.add_argument("--tower-order", default=None, choices=["sequential", "interleaved", "paced"], help="how the two tower streams are fed (model.py::"
-                    "NativeCLIP.tower_order): whole towers one after the other, block by block alternately, or alternately + paced by events")
     ap.add_argument("--no-wgrad-pair", action="store_true", help="with --serial-towers: no wgrad side stream either (every kernel alone on the chip: the "
                     "configuration of the event-timed steps, used for the rocprofv3 / PMC passes)")
     ap.add_argument("--no-dense-text-line", action="store_true", help="skip the extra --dense-text timing that the default line carries")
@@ -256,8 +254,6 @@ def main():
         model.pack_text = False
     if args.serial_towers:
         model.tower_streams = False
-    if args.tower_order:
-        model.tower_order = args.tower_order
     overlap_towers = model.tower_streams
     model.pair_wgrad = not args.no_wgrad_pair
     if args.grad_checkpointing:
@@ -423,7 +419,7 @@ def main():
                        "ddp": bool(world > 1 or args.force_ddp), "bucket_cap_mb": args.bucket_cap_mb,
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "text_tower": text_rows_note,
-                       "tower_streams": (f"image tower on its own stream next to the text tower ({model_ref.tower_order})" if overlap_towers else "one stream"),
+                       "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             # FLOPs of the model as the reference runs it (every caption padded to context_length); the packed text tower executes fewer
             ("step_model_tflops_per_gpu" if not model_ref.pack_text else "step_dense_equivalent_model_tflops_per_gpu"): round(value / world * flops_pair / 1e3, 1),

@@ -164,35 +164,6 @@ _TOWER_STREAMS_DEFAULT = _os.environ.get("OCN_TOWER_STREAMS", "1") != "0"
 _TOWER_SIDE = {}
 
 
-class _Pace:
-    """Event hand-off between the towers' streams when their blocks are enqueued ALTERNATELY (``tower_order = "paced"``): the image
-    tower ("lead", the longer chain) records an event where its block j starts, the text tower's block j ("follow") waits for it -- in
-    the forward; in the backward, where the engine runs text block j right BEFORE image block j, text block j waits for the start
-    of image block j + 1.  The text tower's work is thereby spread over the whole of the image tower's instead of being spent in
-    its first third, so that the image tower's HBM-bound kernels (LayerNorm, attention) find a GEMM of the other tower to share the
-    chip with all the way through."""
-
-    def __init__(self):
-        self.fwd, self.bwd = {}, {}
-
-    @staticmethod
-    def _go(table, role, key_lead, key_follow):
-        if role == "lead":
-            ev = torch.cuda.Event()
-            ev.record()
-            table[key_lead] = ev
-        else:
-            ev = table.get(key_follow)
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-
-    def forward(self, role, j):
-        self._go(self.fwd, role, j, j)
-
-    def backward(self, role, j):
-        self._go(self.bwd, role, j, j + 1)
-
-
 class _AfterStream(torch.autograd.Function):
     """identity whose BACKWARD makes its own stream wait for ``other``.  ``tower_streams = "serial"`` (measurement mode of bench.py: every
     kernel alone on the chip, but each tower on the stream -- and therefore in the caching-allocator pool -- it uses when the towers
@@ -258,13 +229,10 @@ def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, cache, B, L, heads, causal, recompute,
-                seq_off=None, pace=None):
+                seq_off=None):
         p = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj)
-        if pace is not None:
-            pace[0].forward(pace[1], pace[2])
         y, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off)
         ctx.meta = (cache, B, L, heads, causal, recompute, seq_off)
-        ctx.pace = pace
         if recompute:  # block-granular activation recompute (transformer.py:579-581): keep only the block input
             ctx.save_for_backward(x, *p)
         else:
@@ -274,8 +242,6 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         cache, B, L, heads, causal, recompute, seq_off = ctx.meta
-        if ctx.pace is not None:
-            ctx.pace[0].backward(ctx.pace[1], ctx.pace[2])
         t = ctx.saved_tensors
         x, p = t[0], t[1:13]
         (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
@@ -340,7 +306,7 @@ class _BlockFn(torch.autograd.Function):
             _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
-        return (dx, *grads, None, None, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -554,8 +520,8 @@ class ResidualAttentionBlock(nn.Module):  # transformer.py:274-330
     def get_weight_dtype(self):
         return self.mlp.c_fc.weight.dtype
 
-    def forward(self, x, cache, B, L, causal, recompute=False, seq_off=None, pace=None):
-        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute, seq_off, pace)
+    def forward(self, x, cache, B, L, causal, recompute=False, seq_off=None):
+        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute, seq_off)
 
 
 class Transformer(nn.Module):  # transformer.py:476-585
@@ -571,26 +537,11 @@ class Transformer(nn.Module):  # transformer.py:476-585
     def set_grad_checkpointing(self, enable=True, impl="inline"):
         self.grad_checkpointing = enable
 
-    def steps(self, x, cache, B, L, causal, seq_off=None, pace=None, role=None):
-        """generator over the blocks (yields after each one; returns the output): lets NativeCLIP.forward enqueue the two towers'
-        blocks alternately"""
-        rc = self.grad_checkpointing and torch.is_grad_enabled()
-        for j, r in enumerate(self.resblocks):
-            x = r(x, cache, B, L, causal, rc, seq_off, (pace, role, j) if pace is not None else None)
-            yield
-        return x
-
     def forward(self, x, cache, B, L, causal, seq_off=None):
-        return _drain(self.steps(x, cache, B, L, causal, seq_off))
-
-
-def _drain(gen):
-    """run a step generator to its end and return its value"""
-    try:
-        while True:
-            next(gen)
-    except StopIteration as e:
-        return e.value
+        rc = self.grad_checkpointing and torch.is_grad_enabled()
+        for r in self.resblocks:
+            x = r(x, cache, B, L, causal, rc, seq_off)
+        return x
 
 
 def _set_group_requires_grad(members, requires_grad: bool):  # transformer.py:2034-2041
@@ -671,10 +622,6 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         """``image``: float [B,3,H,W] (already normalised, as the reference's transform produces) or uint8 pixels
         ([B,3,H,W], or [B,H,W,3] as decoders emit them) which are normalised with ``image_mean`` / ``image_std`` in the
         patch kernel."""
-        return _drain(self.steps(image, normalize))
-
-    def steps(self, image, normalize=False, pace=None):
-        """the forward as a generator: yields after the embedding and after every block, returns the features"""
         B = image.shape[0]
         norm = None
         if image.dtype == torch.uint8:
@@ -688,8 +635,7 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         T = self.grid_size[0] * self.grid_size[1] + 1
         x = _VisionEmbedFn.apply(image, self.conv1.weight, self.class_embedding, self.positional_embedding,
                                  self.ln_pre.weight, self.ln_pre.bias, self._cache, self.patch_size[0], norm)
-        yield
-        x = yield from self.transformer.steps(x, self._cache, B, T, False, None, pace, "lead")
+        x = self.transformer(x, self._cache, B, T, False)
         return _HeadFn.apply(x, self.ln_post.weight, self.ln_post.bias, self.proj, None, self._cache, B, T, normalize)
 
 
@@ -759,9 +705,6 @@ class NativeCLIP(nn.Module):
         # True: image tower on a stream of its own next to the text tower (see _TOWER_SIDE); False: one stream; "serial": the same two
         # streams, one tower at a time (bench.py's event-timed steps)
         self.tower_streams = _TOWER_STREAMS_DEFAULT
-        # how the two streams are fed: "sequential" (the whole image tower is enqueued, then the whole text tower), "interleaved" (block
-        # by block alternately), "paced" (alternately + _Pace's events)
-        self.tower_order = _os.environ.get("OCN_TOWER_ORDER", "sequential")
         self.pair_wgrad = True  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
@@ -823,23 +766,17 @@ class NativeCLIP(nn.Module):
         return self.visual(image, normalize)
 
     def encode_text(self, text, normalize: bool = False, _pack=None):
-        return _drain(self._text_steps(text, normalize, _pack))
-
-    def _text_steps(self, text, normalize=False, _pack=None, pace=None):
-        """encode_text as a generator: yields after the embedding and after every block, returns the features"""
         B, L = text.shape
         if L != self.context_length:
             raise RuntimeError(f"text length {L} != context_length {self.context_length}")
         if self.pack_text:
             pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size)).finish()
             x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)
-            yield
-            x = yield from self.transformer.steps(x, self._cache, B, L, True, pack.layout, pace, "follow")
+            x = self.transformer(x, self._cache, B, L, True, pack.layout)
             # L = 0: last_row holds absolute rows of the packed matrix
             return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, pack.last_row, self._cache, B, 0, normalize)
         x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
-        yield
-        x = yield from self.transformer.steps(x, self._cache, B, L, True, None, pace, "follow")
+        x = self.transformer(x, self._cache, B, L, True)
         idx = ops.argmax_rows(text.contiguous())
         return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, idx, self._cache, B, L, normalize)
 
@@ -863,33 +800,13 @@ class NativeCLIP(nn.Module):
                 side = _TOWER_SIDE[dev] = torch.cuda.Stream(device=dev)
             serial = self.tower_streams == "serial"  # one tower at a time, on the same two streams (see _AfterStream)
             side.wait_stream(cur)
-            if serial or self.tower_order == "sequential":
-                with torch.cuda.stream(side):
-                    image_features = self.encode_image(image, normalize=True)
-                    if serial and image_features.requires_grad:
-                        image_features = _AfterStream.apply(image_features, cur)
-                if serial:
-                    cur.wait_stream(side)
-                text_features = self.encode_text(text, normalize=True, _pack=pack)
-            else:
-                # the towers' blocks are enqueued alternately (image block j on the side stream, then text block j on the caller's): the
-                # autograd engine then runs their backwards alternately too (text j, image j, text j-1, ...); "paced" adds _Pace's events
-                pace = _Pace() if self.tower_order == "paced" else None
-                gi, gt = self.visual.steps(image, True, pace), self._text_steps(text, True, pack, pace)
-                image_features = text_features = None
-                done_i = done_t = False
-                while not (done_i and done_t):
-                    if not done_i:
-                        with torch.cuda.stream(side):
-                            try:
-                                next(gi)
-                            except StopIteration as e:
-                                image_features, done_i = e.value, True
-                    if not done_t:
-                        try:
-                            next(gt)
-                        except StopIteration as e:
-                            text_features, done_t = e.value, True
+            with torch.cuda.stream(side):
+                image_features = self.encode_image(image, normalize=True)
+                if serial and image_features.requires_grad:
+                    image_features = _AfterStream.apply(image_features, cur)
+            if serial:
+                cur.wait_stream(side)
+            text_features = self.encode_text(text, normalize=True, _pack=pack)
             image.record_stream(side)
             cur.wait_stream(side)
             image_features.record_stream(cur)

@@ -517,13 +517,10 @@ def test_overlapped_towers_equal_one_stream():
     state = init_state_dict(cfg, seed=2, perturb=True)
     batches = [synthetic_batch(cfg, 128, seed=20 + i, device="cuda") for i in range(4)]
     res = {}
-    for mode in (True, "interleaved", "paced", "serial", False):
+    for mode in (True, "serial", False):
         model = _build(cfg, state)
         assert model.tower_streams is True, "overlapped towers must be the default"
-        if mode in ("interleaved", "paced"):  # two streams, the towers' blocks enqueued alternately (+ _Pace's events)
-            model.tower_order = mode
-        else:
-            model.tower_streams, model.tower_order = mode, "sequential"
+        model.tower_streams = mode
         opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=1e-4, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
         loss_fn, losses, first = NativeClipLoss(), [], None
         for b in batches:
@@ -539,8 +536,7 @@ def test_overlapped_towers_equal_one_stream():
         torch.cuda.synchronize()
         res[mode] = (first, losses, {k: p.detach().clone() for k, p in model.named_parameters()})
     f0, l0, p0 = res[False]
-    for mode, what in ((True, "overlapped"), ("interleaved", "overlapped, blocks enqueued alternately"), ("paced", "overlapped, alternately + paced by events"),
-                       ("serial", "one-at-a-time on two streams (bench.py's event-timed steps)")):
+    for mode, what in ((True, "overlapped"), ("serial", "one-at-a-time on two streams (bench.py's event-timed steps)")):
         f1, l1, p1 = res[mode]
         assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])
         gw = max((float((f1[2][k] - f0[2][k]).norm() / (f0[2][k].norm() + 1e-30)), k) for k in f0[2])

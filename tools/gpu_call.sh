@@ -23,14 +23,6 @@ if has ab; then
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --gemm-variant $V 2>&1 | grep '^{' > $O/${TAG}_bench_variant_$V.json
   done; stamp ab
 fi
-if has order; then  # how the two tower streams are fed: A/B/C in one process each, same box
-  for ORD in sequential interleaved paced sequential paced; do
-    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tower-order $ORD 2>&1 | grep '^{' >> $O/${TAG}_order_$ORD.json
-  done
-  for ORD in sequential paced; do
-    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --tower-order $ORD --force-ddp 2>&1 | grep '^{' >> $O/${TAG}_order_ddp_$ORD.json
-  done; stamp order
-fi
 if has buckets; then  # packed text attention launched in buckets of equal block count vs every workgroup sized for context_length
   for BK in 1 0 1 0; do
     OCN_ATTN_BUCKETS=$BK timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_buckets_$BK.json
