@@ -189,6 +189,7 @@ int ocn_token_embed_bwd_sorted_varlen(const int64_t* sorted_tokens, const int64_
  *   (L = 0: idx holds absolute row numbers -- the packed text tower's last_row) */
 int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, ocn_stream_t stream);
 int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream);
+int ocn_gather_rows_bf16(const void* x, const int32_t* idx, void* out, int B, int L, int C, ocn_stream_t stream); /* bf16 x / out, C % 8 == 0 */
 int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
                      ocn_stream_t stream);
 

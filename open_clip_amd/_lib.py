@@ -46,6 +46,7 @@ SIGNATURES = {
     "ocn_token_embed_bwd_sorted_varlen": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],
     "ocn_gather_rows": [_p, _p, _p, _i, _i, _i, _p],
+    "ocn_gather_rows_bf16": [_p, _p, _p, _i, _i, _i, _p],
     "ocn_scatter_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_l2norm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ocn_l2norm_bwd": [_p, _p, _p, _p, _i, _i, _p],

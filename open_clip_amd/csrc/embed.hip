@@ -654,6 +654,26 @@ extern "C" int ocn_gather_rows(const float* x, const int32_t* idx, float* out, i
     return OCN_OK;
 }
 
+// the same gather for a bf16 matrix (the attention output rows of the pooled tokens: A operand of the last block's out-proj)
+__global__ void gather_rows_bf16_kernel(const bf16* __restrict__ x, const int32_t* __restrict__ idx, bf16* __restrict__ out, int B, int L, int C) {
+    const int c8n = C / 8;
+    const long total = (long)B * c8n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8n) * 8;
+        const long b = i / c8n;
+        const int t = idx ? idx[b] : 0;
+        *(bf16x8*)(out + (size_t)b * C + c) = *(const bf16x8*)(x + ((size_t)b * L + t) * C + c);
+    }
+}
+
+extern "C" int ocn_gather_rows_bf16(const void* x, const int32_t* idx, void* out, int B, int L, int C, ocn_stream_t stream) {
+    OCN_CHECK_ARG(x && out && B > 0 && L >= 0 && (L > 0 || idx) && C % 8 == 0, "ocn_gather_rows_bf16: bad arguments");
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(grid_for((long)B * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, idx,
+                       (bf16*)out, B, L, C);
+    OCN_CHECK_LAUNCH("ocn_gather_rows_bf16");
+    return OCN_OK;
+}
+
 extern "C" int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
                                 ocn_stream_t stream) {
     OCN_CHECK_ARG(d && (dx || dx_bf16) && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_scatter_rows: bad arguments");

@@ -310,6 +310,95 @@ class _BlockFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------
+# The LAST residual block of a tower, evaluated only where its output is consumed.
+# Both poolers read ONE row per sequence of the last block's output -- `x[:, 0]` behind ln_post (transformer.py:829-831, 'tok') and
+# `x[arange, text.argmax(-1)]` behind ln_final (:941-944) -- and a residual block is row-wise except inside the attention (where row
+# i reads the K / V of the other rows).  So of the last block only  LN1 -> QKV -> attention  has to run on every row; the out-projection,
+# both residual adds, LN2 and the whole MLP are needed on the B pooled rows alone (1 row in 50 / 43), forward and backward: the rows that
+# are dropped reach neither the features nor any gradient.  Same results as the full block up to fp32 summation order
+# (tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); ``model.pooled_last_block = False`` / OCN_POOLED_LAST_BLOCK=0 runs
+# the full block.  `rows` = absolute row of each sequence's pooled token (int32 [B]); the output is [B, C].
+# ------------------------------------------------------------------------------------------------------
+_POOLED_LAST_BLOCK = _os.environ.get("OCN_POOLED_LAST_BLOCK", "1") != "0"
+
+
+def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None):
+    (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
+    M, C = x.shape
+    h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
+    qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
+    hd = C // heads
+    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd, seq_off)
+    a_p = ops.gather_rows_bf16(a, rows, B, 0)  # [B, C]: from here on only the pooled rows
+    x_p = ops.gather_rows(x, rows, B, 0)
+    xmid_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a_p, cache.get(wo, "n"), ops.empty((B, C), F32, x), bias=bo, resid=x_p)
+    h2_p, _, mean2, rstd2 = ops.layernorm_fwd(xmid_p, ln2w, ln2b)
+    Fd = wfc.shape[0]
+    f_p = ops.empty((B, Fd), BF16, x)
+    g_p = ops.gemm_nt(ops.EPI_BIAS_GELU, h2_p, cache.get(wfc, "n"), ops.empty((B, Fd), BF16, x), bias=bfc, aux=f_p)
+    y_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g_p, cache.get(wproj, "n"), ops.empty((B, C), F32, x), bias=bproj, resid=xmid_p)
+    return y_p, (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p)
+
+
+class _PooledBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, rows, cache, B, L, heads, causal, recompute,
+                seq_off=None):
+        p = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj)
+        y_p, saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off)
+        ctx.meta = (cache, B, L, heads, causal, recompute, seq_off)
+        if recompute:
+            ctx.save_for_backward(x, *p, rows)
+        else:
+            ctx.save_for_backward(x, *p, rows, *saved)
+        return y_p
+
+    @staticmethod
+    def backward(ctx, dy_p):
+        cache, B, L, heads, causal, recompute, seq_off = ctx.meta
+        t = ctx.saved_tensors
+        x, p, rows = t[0], t[1:13], t[13]
+        (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
+        saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off)[1] if recompute else t[14:]
+        (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p) = saved
+        M, C = x.shape
+        Fd = wfc.shape[0]
+        dy16 = _take_twin(dy_p)
+        dy_p = dy_p.contiguous()
+        sizes = [q.numel() for q in p]
+        arena = torch.zeros(sum(sizes), dtype=F32, device=x.device)
+        grads, o = [], 0
+        for q, n in zip(p, sizes):
+            grads.append(arena[o:o + n].view(q.shape))
+            o += n
+        (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
+        need_w = any(ctx.needs_input_grad[1:13])
+        # ---- MLP branch and out-projection: the B pooled rows ----
+        df_p = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((B, Fd), BF16, x), aux=f_p)
+        dh2_p = ops.gemm_nt(ops.EPI_BF16, df_p, cache.get(wfc, "t"), ops.empty((B, C), BF16, x))
+        dxmid_p, dxmid16_p = ops.layernorm_bwd(dh2_p, xmid_p, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy_p, want_f32=True, want_bf16=True)
+        da_p = ops.gemm_nt(ops.EPI_F32, dxmid16_p, cache.get(wo, "t"), ops.empty((B, C), F32, x))
+        if need_w:
+            ops.gemm_tn_accum(dy16, g_p, dwproj, dbproj)
+            ops.gemm_tn_accum(df_p, h2_p, dwfc, dbfc)
+            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, dbo)
+        # ---- attention and everything below it: every row (the pooled rows' queries read all keys / values) ----
+        da = torch.zeros((M, C), dtype=BF16, device=x.device)
+        ops.scatter_rows(da_p, rows, None, B, 0, da)
+        dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
+        dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
+        if need_w:
+            ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv)
+        dres = torch.zeros((M, C), dtype=F32, device=x.device)  # the residual path x -> xmid carries gradient on the pooled rows only
+        ops.scatter_rows(dxmid_p, rows, dres, B, 0, None)
+        dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True)
+        _publish_twin(dx, dx16)
+        if not need_w:
+            grads = [None] * 12
+        return (dx, *grads, None, None, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------------
 # image embedding (transformer.py:793-808)
 # ------------------------------------------------------------------------------------------------------
 class _VisionEmbedFn(torch.autograd.Function):
@@ -537,11 +626,22 @@ class Transformer(nn.Module):  # transformer.py:476-585
     def set_grad_checkpointing(self, enable=True, impl="inline"):
         self.grad_checkpointing = enable
 
-    def forward(self, x, cache, B, L, causal, seq_off=None):
+    def forward(self, x, cache, B, L, causal, seq_off=None, pooled_rows=None):
+        """``pooled_rows`` (int32 [B], absolute rows): the caller only reads these rows of the output -- the last block then runs as
+        _PooledBlockFn and the result is [B, C] (the pooled rows, in order) instead of [M, C]"""
         rc = self.grad_checkpointing and torch.is_grad_enabled()
-        for r in self.resblocks:
+        blocks = list(self.resblocks)
+        last = blocks.pop() if pooled_rows is not None else None
+        for r in blocks:
             x = r(x, cache, B, L, causal, rc, seq_off)
+        if last is not None:
+            x = _PooledBlockFn.apply(x, *last.params(), pooled_rows, cache, B, L, last.n_head, causal, rc, seq_off)
         return x
+
+
+def _pooled_last_block_ok(module) -> bool:
+    """the pooled form of the last block (see _PooledBlockFn) unless switched off on the module or by one of the gradient-stream experiments"""
+    return getattr(module, "pooled_last_block", True) and _POOLED_LAST_BLOCK and not _BF16_GRAD_STREAM and not _LN_PAIR
 
 
 def _set_group_requires_grad(members, requires_grad: bool):  # transformer.py:2034-2041
@@ -581,6 +681,7 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         self.image_size = (image_size, image_size)
         self.patch_size = (patch_size, patch_size)
         self.grid_size = (image_size // patch_size, image_size // patch_size)
+        self.pooled_last_block = True  # the last block only on the class-token rows behind the attention (see _PooledBlockFn)
         self.output_dim = output_dim
         self.width = width
         scale = width ** -0.5
@@ -635,6 +736,10 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         T = self.grid_size[0] * self.grid_size[1] + 1
         x = _VisionEmbedFn.apply(image, self.conv1.weight, self.class_embedding, self.positional_embedding,
                                  self.ln_pre.weight, self.ln_pre.bias, self._cache, self.patch_size[0], norm)
+        if _pooled_last_block_ok(self):
+            rows = torch.arange(B, device=x.device, dtype=torch.int32)
+            x = self.transformer(x, self._cache, B, T, False, None, rows * T)  # the class token's rows; the result is [B, C]
+            return _HeadFn.apply(x, self.ln_post.weight, self.ln_post.bias, self.proj, rows, self._cache, B, 0, normalize)
         x = self.transformer(x, self._cache, B, T, False)
         return _HeadFn.apply(x, self.ln_post.weight, self.ln_post.bias, self.proj, None, self._cache, B, T, normalize)
 
@@ -705,6 +810,9 @@ class NativeCLIP(nn.Module):
         # True: image tower on a stream of its own next to the text tower (see _TOWER_SIDE); False: one stream; "serial": the same two
         # streams, one tower at a time (bench.py's event-timed steps)
         self.tower_streams = _TOWER_STREAMS_DEFAULT
+        # the last block of each tower only where its output is read (see _PooledBlockFn); the image tower has its own switch
+        # (``model.visual.pooled_last_block``)
+        self.pooled_last_block = True
         self.pair_wgrad = True  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
@@ -772,12 +880,20 @@ class NativeCLIP(nn.Module):
         if self.pack_text:
             pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size)).finish()
             x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)
+            if _pooled_last_block_ok(self):
+                x = self.transformer(x, self._cache, B, L, True, pack.layout, pack.last_row)  # [B, C]: the EOT rows
+                rows = torch.arange(B, device=x.device, dtype=torch.int32)
+                return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, rows, self._cache, B, 0, normalize)
             x = self.transformer(x, self._cache, B, L, True, pack.layout)
             # L = 0: last_row holds absolute rows of the packed matrix
             return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, pack.last_row, self._cache, B, 0, normalize)
         x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
-        x = self.transformer(x, self._cache, B, L, True)
         idx = ops.argmax_rows(text.contiguous())
+        if _pooled_last_block_ok(self):
+            rows = torch.arange(B, device=x.device, dtype=torch.int32)
+            x = self.transformer(x, self._cache, B, L, True, None, rows * L + idx)
+            return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, rows, self._cache, B, 0, normalize)
+        x = self.transformer(x, self._cache, B, L, True)
         return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, idx, self._cache, B, L, normalize)
 
     def get_logits(self, image, text):

@@ -347,6 +347,13 @@ def gather_rows(x, idx, B, L):
     return out
 
 
+def gather_rows_bf16(x, idx, B, L):
+    C = x.shape[1]
+    out = empty((B, C), BF16, x)
+    _lib.call("ocn_gather_rows_bf16", _chk(x, BF16, "x"), _chk(idx, torch.int32, "idx"), _chk(out, BF16, "out"), B, L, C, _stream())
+    return out
+
+
 def scatter_rows(d, idx, dx, B, L, dx16=None):
     C = d.shape[1]
     _lib.call("ocn_scatter_rows", _chk(d, F32, "d"), _chk(idx, torch.int32, "idx"), _chk(dx, F32, "dx"), _chk(dx16, BF16, "dx16"), B, L, C, _stream())

@@ -566,3 +566,32 @@ def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
         model(image=batch["image"], text=bad)
     with pytest.raises(IndexError):
         model.encode_text(bad, normalize=True)
+
+
+@pytest.mark.parametrize("variant", ["packed", "dense_text", "recompute", "siglip"])
+def test_pooled_last_block_equals_full_block(variant):
+    """the last block of each tower evaluated only on the pooled rows behind its attention (model.py::_PooledBlockFn) against the full
+    block: the dropped rows reach neither the features nor any gradient, so features, loss and every gradient must agree up to fp32
+    summation order (the weight gradients of the last block sum over B rows instead of M, the rest of the graph is the same)"""
+    cfg = get_model_config("ViT-B-32")
+    siglip = variant == "siglip"
+    state = init_state_dict(cfg, seed=9, perturb=True, siglip=siglip)
+    batch = synthetic_batch(cfg, 24, seed=31, device="cuda")
+    res = {}
+    for pooled in (True, False):
+        model = _build(cfg, state, siglip=siglip)
+        assert model.pooled_last_block and model.visual.pooled_last_block, "the pooled last block must be the default"
+        model.pooled_last_block = model.visual.pooled_last_block = pooled
+        if variant == "dense_text":
+            model.pack_text = False
+        if variant == "recompute":
+            model.set_grad_checkpointing(True)
+        out, loss = _step(model, batch, siglip=siglip)
+        res[pooled] = (out, float(loss), {k: p.grad.clone() for k, p in model.named_parameters()})
+    (o1, l1, g1), (o0, l0, g0) = res[True], res[False]
+    fi = float((o1["image_features"] - o0["image_features"]).abs().max())
+    ft = float((o1["text_features"] - o0["text_features"]).abs().max())
+    worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0)
+    _report(f"pooled vs full last block [{variant}] (ViT-B-32, B=24): features max |diff| {fi:.1e} / {ft:.1e}, loss {l1:.7f} vs {l0:.7f}; "
+            f"worst gradient rel_l2 = {worst[0]:.3e} ({worst[1]})")
+    assert fi <= 1e-6 and ft <= 1e-6 and abs(l1 - l0) <= 2e-6 * abs(l0) and worst[0] <= 2e-5, (fi, ft, l1, l0, worst)

@@ -37,6 +37,11 @@ fi
 if has lngrid; then  # LayerNorm backward: 16-wave workgroups, one per CU (default) against other grid sizes
   timeout 300 python tools/ab_ln_bwd.py 0,128,256,512,1024 > $O/${TAG}_ln_grid.txt 2>&1; stamp lngrid
 fi
+if has pooled; then  # the last block of each tower only on the pooled rows (model.py::_PooledBlockFn) vs the full block
+  for PK in 1 0 1 0; do
+    OCN_POOLED_LAST_BLOCK=$PK timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_pooled_$PK.json
+  done; stamp pooled
+fi
 if has bench; then timeout 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
 if has lines; then
   timeout 300 python bench.py --steps 8 --warmup 2 --h2d $QUIET > $O/${TAG}_bench_h2d.log 2>&1
