@@ -407,6 +407,17 @@ def test_text_embed_and_pool_kernels(dev):
     dfull = torch.zeros(B * L, C, device=dev)
     ops.scatter_rows(pooled, idx, dfull, B, L)
     assert torch.equal(dfull.reshape(B, L, C)[torch.arange(B), idx.long()], pooled) and float(dfull.abs().sum()) == float(pooled.abs().sum())
+    # the bf16 gather and the absolute-row (L = 0) forms that the pooled last block uses (model.py::_PooledBlockFn)
+    rows = (torch.arange(B, device=dev) * L + idx.long()).to(torch.int32)
+    x16 = x.bfloat16()
+    assert torch.equal(ops.gather_rows_bf16(x16, rows, B, 0), x16[rows.long()])
+    assert torch.equal(ops.gather_rows_bf16(x16, idx, B, L), x16[rows.long()])
+    assert torch.equal(ops.gather_rows(x, rows, B, 0), pooled)
+    d16 = torch.zeros(B * L, C, device=dev, dtype=torch.bfloat16)
+    ops.scatter_rows(pooled, rows, None, B, 0, d16)  # bf16 target only
+    untouched = torch.ones(B * L, dtype=torch.bool, device=dev)
+    untouched[rows.long()] = False
+    assert torch.equal(d16[rows.long()], pooled.bfloat16()) and float(d16[untouched].float().abs().max()) == 0.0
     y, y16, inv = ops.l2norm_fwd(pooled)
     check("l2norm_fwd", y, torch.nn.functional.normalize(pooled, dim=-1), rel=1e-6)
     pr = pooled.clone().requires_grad_(True)
