@@ -277,6 +277,10 @@ def main():
                           f"identical to the padded tower (tests/test_model_gpu.py::test_packed_text_tower_equals_dense_text_tower); --dense-text runs all rows")
     else:
         text_rows_note = f"dense: all {ctx_len} positions of every caption (as the reference)"
+    from open_clip_amd.model import _pooled_last_block_ok
+    last_block_note = ("out-projection, LN2 and MLP of each tower's last block on the pooled rows only (the only rows the poolers read; same features and "
+                       "gradients, tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); OCN_POOLED_LAST_BLOCK=0 runs every row"
+                       if (_pooled_last_block_ok(model) and _pooled_last_block_ok(model.visual)) else "every row (as the reference)")
     pipe = None
     if args.h2d:
         # decoded pixels as a loader hands them over: uint8 [B,H,W,3] in pinned host memory (synthetic; a pool of 2 batches is cycled)
@@ -420,6 +424,7 @@ def main():
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "text_tower": text_rows_note,
                        "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
+                       "last_block": last_block_note,
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             # FLOPs of the model as the reference runs it (every caption padded to context_length); the packed text tower executes fewer
             ("step_model_tflops_per_gpu" if not model_ref.pack_text else "step_dense_equivalent_model_tflops_per_gpu"): round(value / world * flops_pair / 1e3, 1),
