@@ -90,3 +90,63 @@ def test_distributed_loss_semantics_match_reference(world):
         assert _close(img.grad, g[f"r{rank}/siglip/bidir/dimg"], 1e-5)
         assert _close(s.grad, g[f"r{rank}/siglip/bidir/dscale"], 1e-5)
         assert _close(b.grad, g[f"r{rank}/siglip/bidir/dbias"], 1e-5)
+
+
+def test_pruned_towers_are_exact_in_the_oracle():
+    """The two structural savings of the native towers, stated on the CPU oracle in float64 (independent of any kernel):
+    (1) packed text: dropping every position behind the pooled EOT token changes nothing -- under the causal mask (transformer.py:1716-1722)
+        position l only reads positions <= l, and ``text_global_pool`` (:941-944) reads x[b, argmax];
+    (2) pooled last block: the poolers read one row per sequence of the last block's output, and a residual block is row-wise except
+        inside the attention, so everything behind the last block's attention can run on the pooled rows alone.
+    Features AND every parameter gradient of the pruned evaluation equal the reference evaluation's to float64 round-off."""
+    cfg = get_model_config("tiny-test")
+    state = {k: v.double() for k, v in init_state_dict(cfg, seed=4, perturb=True).items()}
+    batch = synthetic_batch(cfg, 5, seed=3)
+    image, text = batch["image"].double(), batch["text"]
+    v, t = cfg["vision_cfg"], cfg["text_cfg"]
+
+    def last_block_on_rows(x, p, pre, heads, causal, pick):
+        """resblock (oracle/clip_oracle.py::resblock) with everything behind the attention evaluated on the rows ``pick(x)`` selects"""
+        a = O.attention(O.layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]), p, pre, heads, causal)
+        xm = pick(x) + pick(a)
+        h = O.layer_norm(xm, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
+        h = O.gelu_erf(h @ p[pre + "mlp.c_fc.weight"].t() + p[pre + "mlp.c_fc.bias"])
+        return xm + h @ p[pre + "mlp.c_proj.weight"].t() + p[pre + "mlp.c_proj.bias"]
+
+    def pruned_image(p):
+        ps, width = v["patch_size"], v["width"]
+        B, Cin, H, W = image.shape
+        gh, gw = H // ps, W // ps
+        w = p["visual.conv1.weight"].reshape(width, Cin * ps * ps)
+        patches = image.reshape(B, Cin, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * ps * ps)
+        x = torch.cat([p["visual.class_embedding"].reshape(1, 1, width).expand(B, 1, width), patches @ w.t()], dim=1) + p["visual.positional_embedding"]
+        x = O.layer_norm(x, p["visual.ln_pre.weight"], p["visual.ln_pre.bias"])
+        heads = width // v.get("head_width", 64)
+        x = O.transformer(x, p, "visual.transformer.", v["layers"] - 1, heads, causal=False)
+        y = last_block_on_rows(x, p, f"visual.transformer.resblocks.{v['layers'] - 1}.", heads, False, lambda z: z[:, 0])
+        return O.l2_normalize(O.layer_norm(y, p["visual.ln_post.weight"], p["visual.ln_post.bias"]) @ p["visual.proj"])
+
+    def pruned_text(p):
+        feats = []
+        for b in range(text.shape[0]):  # one sequence at a time, cut behind its EOT token: the packed rows of the native tower
+            n = int(text[b].argmax()) + 1
+            x = (p["token_embedding.weight"][text[b, :n]] + p["positional_embedding"][:n]).unsqueeze(0)
+            x = O.transformer(x, p, "transformer.", t["layers"] - 1, t["heads"], causal=True)
+            y = last_block_on_rows(x, p, f"transformer.resblocks.{t['layers'] - 1}.", t["heads"], True, lambda z: z[:, -1])
+            feats.append(O.layer_norm(y, p["ln_final.weight"], p["ln_final.bias"]) @ p["text_projection"])
+        return O.l2_normalize(torch.cat(feats))
+
+    def run(fi, ft):
+        p = {k: x.clone().requires_grad_(True) for k, x in state.items()}
+        i, tt = fi(p), ft(p)
+        loss = O.clip_loss(i, tt, p["logit_scale"].exp())
+        loss = loss if torch.is_tensor(loss) else loss[0]
+        loss.backward()
+        return i.detach(), tt.detach(), {k: x.grad for k, x in p.items() if x.grad is not None}
+
+    i0, t0, g0 = run(lambda p: O.encode_image(image, p, cfg), lambda p: O.encode_text(text, p, cfg))
+    i1, t1, g1 = run(pruned_image, pruned_text)
+    assert float((i1 - i0).abs().max()) < 1e-12 and float((t1 - t0).abs().max()) < 1e-12
+    assert set(g0) == set(g1)
+    worst = max(float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-300)) for k in g0)
+    assert worst < 1e-10, worst
