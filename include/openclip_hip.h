@@ -68,13 +68,14 @@ int ocn_gemm_tn_accum2(const void* A1, int lda1, const void* B1, int ldb1, float
                        const void* A2, int lda2, const void* B2, int ldb2, float* dW2, int ldw2, float* dbias2, int N2,
                        int M, int K, float alpha, ocn_stream_t stream);
 
-/* The same with a caller-provided scratch buffer: when ocn_gemm_tn_workspace_bytes(M, N, K) > 0 (many M-splits accumulating into a
- * small dW: the out-proj / QKV weight gradients) and `workspace` holds that many bytes, every split stores its partial tile to its own
- * slab and a second kernel sums the slabs into dW, instead of 20..60-way contended fp32 atomics.  The query returns 0 (atomics) unless
- * developer knob 12 = 2: measured -5 % on the out-proj shapes and nothing on the training step. */
-int64_t ocn_gemm_tn_workspace_bytes(int M, int N, int K);
-int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
-                         float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream);
+/* Run-to-run reproducible form of ocn_gemm_tn_accum (same arguments, same result up to fp32 summation ORDER, which here is fixed): no
+ * two workgroups add into one address.  Shapes the hand-scheduled kernel takes (ocn_gemm_tn_det_workspace_bytes(M, N, K) > 0) need that
+ * many bytes of 16-byte aligned scratch: every M-split stores its partial dW tile (and bias row) to its own slab and a second kernel sums
+ * the slabs in split order; other shapes run the general kernel with one M-split and need no scratch.  The reference's counterpart is
+ * torch.use_deterministic_algorithms for its own GEMMs; cost here: one extra pass over splits x N x K floats per launch. */
+int64_t ocn_gemm_tn_det_workspace_bytes(int M, int N, int K);
+int ocn_gemm_tn_accum_det(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
+                          float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream);
 
 /* ---- casts -------------------------------------------------------------------------------------
  * amp_bf16 policy (precision.py:6-16): fp32 master weights, bf16 GEMM operands. */
@@ -96,13 +97,6 @@ int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf
 int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, int M,
                       int C, ocn_stream_t stream);
-/* The same with the residual gradient exchanged in bf16: dres may come as dres_hi alone (bf16: the form the block backward uses --
- * 10 instead of 16 bytes per element: dy 2 + x 4 + dres 2 in, dx 2 out, the bf16 dx being the next GEMM's operand anyway) or as a
- * (hi, lo) pair (value = hi + lo, 16 mantissa bits) with dx_lo (next to dx_bf16 as its hi half) replacing dx_f32. */
-int ocn_layernorm_bwd_pair(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean, const float* rstd,
-                           const float* dres, const void* dres_hi, const void* dres_lo, float* dx_f32, void* dx_bf16, void* dx_lo,
-                           float* dw, float* db, int M, int C, ocn_stream_t stream);
-
 /* ---- attention core (transformer.py:199-244: head split + F.scaled_dot_product_attention) ------
  * qkv bf16 [B*L, 3*H*64] (q | k | v column blocks, heads contiguous inside each: the layout F.linear with
  * in_proj_weight produces, transformer.py:169); out bf16 [B*L, H*64]; lse fp32 [B*H*L] (natural log).

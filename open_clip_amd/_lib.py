@@ -17,14 +17,13 @@ _p, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 SIGNATURES = {
     "ocn_gemm_nt": [_i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p],
     "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
+    "ocn_gemm_tn_accum_det": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p, _l, _p],
     "ocn_gemm_tn_accum2": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p],
-    "ocn_gemm_tn_accum_ws": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p, _l, _p],
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
     "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "ocn_layernorm_bwd_pair": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_fwd_hd": [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
@@ -75,7 +74,7 @@ DEBUG_SIGNATURES = {
     "ocn_debug_nt5_trace": [_p],
     "ocn_debug_stream_with_cu_mask": [_p, _i, _p],
 }
-_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_workspace_bytes": ([_i, _i, _i], _l),
+_SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_det_workspace_bytes": ([_i, _i, _i], _l),
             "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l)}
 
 _lib = None

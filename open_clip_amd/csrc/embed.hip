@@ -204,19 +204,21 @@ __global__ __launch_bounds__(128) void token_embed_bwd_sorted_kernel(const int64
                                                                      const T* __restrict__ dx, float* __restrict__ dtable, long n, int C,
                                                                      int vocab, int CH) {
     const long i0 = (long)blockIdx.x * CH, i1 = min(n, i0 + CH);
+    // a run is identified by the CLAMPED id (ids outside the vocabulary share row 0 / vocab - 1), so whether a run continues into the
+    // neighbouring chunk is decided on clamped ids too: two chunks must never both take one row for a complete run and plain-store it
+    auto clamped = [&](long i) -> long {
+        const long t = keys[i];
+        return t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    };
     for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         long cur = -1, seg_start = i0;
         for (long i = i0; i <= i1; ++i) {
-            long tok = -2;
-            if (i < i1) {
-                tok = keys[i];
-                tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-            }
+            const long tok = i < i1 ? clamped(i) : -2;
             if (tok != cur) {
                 if (cur >= 0) {
-                    const bool closed_l = seg_start > i0 || i0 == 0 || keys[i0 - 1] != keys[i0];
-                    const bool closed_r = i < i1 || i1 == n || keys[i1] != keys[i1 - 1];
+                    const bool closed_l = seg_start > i0 || i0 == 0 || clamped(i0 - 1) != clamped(i0);
+                    const bool closed_r = i < i1 || i1 == n || clamped(i1) != clamped(i1 - 1);
                     float* d = dtable + (size_t)cur * C + c;
                     if (closed_l && closed_r) {
                         *(f32x4*)d = acc;

@@ -472,34 +472,30 @@ extern "C" int ocn_set_gemm_variant(int nt_variant) {
     return OCN_OK;
 }
 
-extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
-                                    float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream);
-
-extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
-                                 float* dbias, float alpha, ocn_stream_t stream) {
-    return ocn_gemm_tn_accum_ws(A, lda, B, ldb, dW, ldw, M, N, K, dbias, alpha, nullptr, 0, stream);
-}
-
-extern "C" int64_t ocn_gemm_tn_workspace_bytes(int M, int N, int K) { return ocn_tn5_workspace_bytes(M, N, K); }
-
-extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
-                                    float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream) {
+namespace {
+// shared body of ocn_gemm_tn_accum / ocn_gemm_tn_accum_det.  `det`: no two workgroups ever add into the same address -- the hand-scheduled
+// kernel stores per-split slabs into `workspace` and sums them in split order, the general kernel runs with ONE M-split.
+int tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias, float alpha, bool det,
+             void* workspace, int64_t workspace_bytes, ocn_stream_t stream) {
     OCN_CHECK_ARG(A && B && dW, "ocn_gemm_tn_accum: null operand");
     OCN_CHECK_ARG(M > 0 && N > 0 && K > 0, "ocn_gemm_tn_accum: bad shape M=%d N=%d K=%d", M, N, K);
     OCN_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "ocn_gemm_tn_accum: N, K, lda, ldb must be multiples of 8");
     OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "ocn_gemm_tn_accum: operands must be 16-byte aligned");
     GemmTnArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.dW = dW; a.dbias = dbias;
-    a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.ablate = 0; a.nsplit = 0;
-    {   // the workspace is used only when it is exactly what the query asked for (same shape, same knobs)
-        const long need = ocn_tn5_workspace_bytes(M, N, K);
-        a.ws = (workspace && need > 0 && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dW & 15) == 0) ? (float*)workspace : nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.ablate = 0; a.nsplit = 0; a.ws = nullptr;
+    const long need = det ? ocn_tn5_workspace_bytes(M, N, K) : 0;
+    if (det && need > 0) {
+        OCN_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dW & 15) == 0 && ldw % 4 == 0,
+                      "ocn_gemm_tn_accum_det: needs %ld bytes of 16-byte aligned workspace (ocn_gemm_tn_det_workspace_bytes) and an aligned dW", need);
+        a.ws = (float*)workspace;
     }
     const bool big = (long)M * N * K >= (1L << 31) && N >= 256 && K >= 256;
-    if (g_tn_variant == 3 || (g_tn_variant == 0 && big)) {  // hand-scheduled 256x256 kernel (gemm_tn5.hip); falls through if the shape does not fit it
+    if ((!det && (g_tn_variant == 3 || (g_tn_variant == 0 && big))) || (det && need > 0)) {  // hand-scheduled 256x256 kernel (gemm_tn5.hip); falls through if the shape does not fit it
         const int rc = ocn_launch_tn5(a, (hipStream_t)stream);
         if (rc < 0) ocn_set_error("ocn_gemm_tn_accum: launch failed");
         if (rc <= 0) return rc;
+        a.ws = nullptr;
     }
     a.A2 = a.B2 = nullptr; a.dW2 = a.dbias2 = nullptr; a.lda2 = a.ldb2 = a.ldw2 = a.N2 = a.ntile1 = a.ntile_all = 0;
     const int T = 128, RS = 64;  // the general kernel: 128x128 tile of dW, 64 reduction rows per step, M split to ~6 workgroups per CU
@@ -507,7 +503,7 @@ extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int l
     a.tiles_k = ocn_cdiv(K, T);
     const int ntile = a.tiles_n * a.tiles_k;
     const int msteps = ocn_cdiv(M, RS);
-    int splits = ocn_cdiv(1536, ntile);
+    int splits = det ? 1 : ocn_cdiv(1536, ntile);
     if (splits > msteps) splits = msteps;
     if (splits < 1) splits = 1;
     a.chunk = ocn_cdiv(msteps, splits) * RS;
@@ -516,6 +512,19 @@ extern "C" int ocn_gemm_tn_accum_ws(const void* A, int lda, const void* B, int l
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
     OCN_CHECK_LAUNCH("ocn_gemm_tn_accum");
     return OCN_OK;
+}
+}  // namespace
+
+extern "C" int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K,
+                                 float* dbias, float alpha, ocn_stream_t stream) {
+    return tn_accum(A, lda, B, ldb, dW, ldw, M, N, K, dbias, alpha, false, nullptr, 0, stream);
+}
+
+extern "C" int64_t ocn_gemm_tn_det_workspace_bytes(int M, int N, int K) { return ocn_tn5_workspace_bytes(M, N, K); }
+
+extern "C" int ocn_gemm_tn_accum_det(const void* A, int lda, const void* B, int ldb, float* dW, int ldw, int M, int N, int K, float* dbias,
+                                     float alpha, void* workspace, int64_t workspace_bytes, ocn_stream_t stream) {
+    return tn_accum(A, lda, B, ldb, dW, ldw, M, N, K, dbias, alpha, true, workspace, workspace_bytes, stream);
 }
 
 // Two weight gradients over the SAME rows and the same K in one launch:  dW1[N1,K] += alpha * A1[M,N1]^T . B1[M,K]  and

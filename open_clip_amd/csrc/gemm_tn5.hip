@@ -257,8 +257,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     const int lr = lane & 31;
     if (a.ablate & 1) return;
     if (a.ws) {
-        // many splits onto a small dW: the 20..60-way contended atomics are what the epilogue spends its time on (26-37 % of the
-        // launch for the out-proj shapes) -> every split stores its tile to its own slab, tn5_reduce_kernel sums the slabs
+        // reproducible form (ocn_gemm_tn_accum_det): every split stores its tile to its own slab and tn5_reduce_kernel sums the slabs
+        // in split order -- no atomics, the same bits on every run (also what removes the 20..60-way contended atomics of the small
+        // out-proj shapes: -5 % there, nothing on the step, profiles/r01_tn5_two_stage_epilogue.txt)
         float* slab = a.ws + (size_t)split * a.N * a.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -273,12 +274,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
                 }
             }
         }
-        // dbias stays on atomics: N values per workgroup, negligible
+        // bias partials: the tiles_k workgroups of a split that share an A strip each summed the steps kt == tk (mod tiles_k)
         if (BIAS && lr == 0) {
+            float* bslab = a.ws + (size_t)a.nsplit * a.N * a.K + ((size_t)split * a.tiles_k + tk) * a.N;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gn = n0 + wn * 128 + wk * 32 + mfma32_row(r, lane);
-                if (gn < a.N) unsafeAtomicAdd(a.dbias + gn, a.alpha * accb[r]);
+                if (gn < a.N) bslab[gn] = accb[r];
             }
         }
         return;
@@ -305,9 +307,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     }
 }
 
-// dW[n,k] += alpha * sum_s ws[s][n][k]
+// dW[n,k] += alpha * sum_s ws[s][n][k] (slabs summed in split order);  dbias[n] += alpha * sum_p bias_slabs[p][n]
 __global__ __launch_bounds__(256) void tn5_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int N, int K, int ldw,
-                                                         int nsplit, float alpha) {
+                                                         int nsplit, float alpha, float* __restrict__ dbias, int nbias_parts) {
     const long total4 = (long)N * K / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -316,6 +318,14 @@ __global__ __launch_bounds__(256) void tn5_reduce_kernel(const float* __restrict
         const int n = (int)(e / K), k = (int)(e % K);
         float* d = dW + (size_t)n * ldw + k;
         *(f32x4*)d = *(const f32x4*)d + acc * alpha;
+    }
+    if (dbias) {
+        const float* bs = ws + (size_t)nsplit * N * K;
+        for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+            float acc = 0.f;
+            for (int p = 0; p < nbias_parts; ++p) acc += bs[(size_t)p * N + n];
+            dbias[n] += acc * alpha;
+        }
     }
 }
 
@@ -335,21 +345,22 @@ int tn5_splits(int M, int N, int K, int num_cu, int over) {
 }  // namespace
 extern int g_ocn_tuning[16];
 
-long ocn_tn5_workspace_bytes(int M, int N, int K) {
-    // Measured (profiles/r01_tn5_two_stage_epilogue.txt): -5 % on the two out-proj shapes, nothing on QKV, nothing on the step (the
-    // extra launch and the 64 MB scratch allocation eat it) -> off unless developer knob 12 = 2 asks for it.
-    if (g_ocn_tuning[12] != 2) return 0;
-    if (N % 8 || K % 4 || (long)M * N * K < (1L << 31) || N < 256 || K < 256) return 0;
-    int n = g_tn5_num_cu;
-    if (n == 0) {
-        int dev = 0;
+static int tn5_cus() {
+    if (g_tn5_num_cu == 0) {
+        int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_tn5_num_cu = n;
     }
-    const int splits = tn5_splits(M, N, K, n, g_ocn_tuning[11] > 0 ? g_ocn_tuning[11] : 1);
-    // worth it when many workgroups hit every address (measured: >= 9 splits) and the slabs stay small next to the operands
-    if (splits < 9 || (long)splits * N * K * 4 > (256L << 20)) return 0;
-    return (long)splits * N * K * 4;
+    return g_tn5_num_cu;
+}
+
+// scratch of the reproducible launch: one fp32 slab of dW per M-split + one bias row per (split, k-tile); 0 = shape not taken by this
+// kernel (the caller uses the general kernel with one split)
+long ocn_tn5_workspace_bytes(int M, int N, int K) {
+    if (N % 8 || K % 8 || (long)M * N * K < (1L << 31) || N < 256 || K < 256) return 0;
+    const int splits = tn5_splits(M, N, K, tn5_cus(), 1);
+    return ((long)splits * N * K + (long)splits * ocn_cdiv(K, 256) * N) * 4;
 }
 
 int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
@@ -390,14 +401,14 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     a.nsplit = splits;
     a.ntile1 = a.ntile_all = ntile;  // single problem
     a.A2 = a.B2 = nullptr; a.dW2 = a.dbias2 = nullptr; a.lda2 = a.ldb2 = a.ldw2 = a.N2 = 0;
-    if (a.ws && (a.ldw % 4 || a.K % 4)) a.ws = nullptr;
+    if (a.ws && (a.ldw % 4 || a.K % 4 || g_ocn_tuning[11] > 1 || g_ocn_tuning[15] > 0)) return 1;  // (the scratch was sized for the default split)
     if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
     else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
     if (a.ws) {
         const long total4 = (long)a.N * a.K / 4;
         int grid = (int)((total4 + 255) / 256);
         if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(tn5_reduce_kernel, dim3(grid), dim3(256), 0, st, a.ws, a.dW, a.N, a.K, a.ldw, splits, a.alpha);
+        hipLaunchKernelGGL(tn5_reduce_kernel, dim3(grid), dim3(256), 0, st, a.ws, a.dW, a.N, a.K, a.ldw, splits, a.alpha, a.dbias, splits * a.tiles_k);
     }
     if (hipGetLastError() != hipSuccess) return OCN_ERR_LAUNCH;
     return OCN_OK;

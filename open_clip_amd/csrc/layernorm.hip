@@ -78,9 +78,7 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                                                       const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
                                                       float* __restrict__ dx32, bf16* __restrict__ dx16,
-                                                      float* __restrict__ dw, float* __restrict__ db, int M, int C,
-                                                      const bf16* __restrict__ dres_hi, const bf16* __restrict__ dres_lo,
-                                                      bf16* __restrict__ dx_lo) {
+                                                      float* __restrict__ dw, float* __restrict__ db, int M, int C) {
     constexpr int BW = ln_bwd_waves<NV>();
     __shared__ float red[(BW + 1) / 2][NV * 256 * 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -107,14 +105,6 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                 // the residual gradient is fetched together with x and dy (not after the row reductions): one memory
                 // round trip per row instead of two
                 if (dres) dr[i] = NT ? __builtin_nontemporal_load((const f32x4*)(dres + (size_t)row * C + c)) : *(const f32x4*)(dres + (size_t)row * C + c);
-                if (dres_hi) {  // residual gradient handed over in bf16 (lo == NULL), or as a (hi, lo) pair: value = hi + lo (16 mantissa bits)
-                    const bf16x4 h4 = *(const bf16x4*)(dres_hi + (size_t)row * C + c);
-                    dr[i] = (f32x4){bf2f(h4[0]), bf2f(h4[1]), bf2f(h4[2]), bf2f(h4[3])};
-                    if (dres_lo) {
-                        const bf16x4 l4 = *(const bf16x4*)(dres_lo + (size_t)row * C + c);
-                        dr[i] += (f32x4){bf2f(l4[0]), bf2f(l4[1]), bf2f(l4[2]), bf2f(l4[3])};
-                    }
-                }
                 const f32x4 xv = NT ? __builtin_nontemporal_load((const f32x4*)(x + (size_t)row * C + c)) : *(const f32x4*)(x + (size_t)row * C + c);
                 f32x4 dy;
                 if (DY32) {
@@ -151,10 +141,6 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                 if (dx16) {
                     bf16x4 o4 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
                     *(bf16x4*)(dx16 + (size_t)row * C + c) = o4;
-                    if (dx_lo) {  // lo = what the bf16 rounding of dx left out (dx16 is the hi half: the next GEMM's operand)
-                        bf16x4 l4 = {f2bf(o[0] - bf2f(o4[0])), f2bf(o[1] - bf2f(o4[1])), f2bf(o[2] - bf2f(o4[2])), f2bf(o[3] - bf2f(o4[3]))};
-                        *(bf16x4*)(dx_lo + (size_t)row * C + c) = l4;
-                    }
                 }
             }
         }
@@ -225,15 +211,14 @@ void launch_fwd(hipStream_t st, const float* x, const float* w, const float* b, 
 }
 template <int NV>
 void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C,
-                const bf16* dres_hi, const bf16* dres_lo, bf16* dx_lo) {
+                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C) {
     const bool nt = g_ocn_tuning[8] != 1;  // developer knob 8 = 1: default cache policy everywhere
     if (dy_is_f32) {
-        if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
-        else ln_bwd_kernel<NV, true, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
+        if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+        else ln_bwd_kernel<NV, true, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
     } else {
-        if (nt) ln_bwd_kernel<NV, false, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
-        else ln_bwd_kernel<NV, false, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo);
+        if (nt) ln_bwd_kernel<NV, false, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+        else ln_bwd_kernel<NV, false, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
     }
 }
 
@@ -257,35 +242,20 @@ extern "C" int ocn_layernorm_fwd(const float* x, const float* w, const float* b,
     return OCN_OK;
 }
 
-extern "C" int ocn_layernorm_bwd_pair(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                                      const float* rstd, const float* dres, const void* dres_hi, const void* dres_lo, float* dx_f32,
-                                      void* dx_bf16, void* dx_lo, float* dw, float* db, int M, int C, ocn_stream_t stream);
-
 extern "C" int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                                  const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db,
                                  int M, int C, ocn_stream_t stream) {
-    return ocn_layernorm_bwd_pair(dy, dy_is_f32, x, w, mean, rstd, dres, nullptr, nullptr, dx_f32, dx_bf16, nullptr, dw, db, M, C, stream);
-}
-
-extern "C" int ocn_layernorm_bwd_pair(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                                      const float* rstd, const float* dres, const void* dres_hi_, const void* dres_lo_, float* dx_f32,
-                                      void* dx_bf16, void* dx_lo_, float* dw, float* db, int M, int C, ocn_stream_t stream) {
     OCN_CHECK_ARG(dy && x && w && mean && rstd && dw && db && (dx_f32 || dx_bf16), "ocn_layernorm_bwd: null operand");
-    OCN_CHECK_ARG(!(dres_lo_ && !dres_hi_) && !(dres && dres_hi_), "ocn_layernorm_bwd_pair: dres is fp32 OR bf16 (hi alone) OR a (hi, lo) pair");
-    OCN_CHECK_ARG(!dx_lo_ || dx_bf16, "ocn_layernorm_bwd_pair: dx_lo needs dx_bf16 (its hi half)");
-    const bf16* dres_hi = (const bf16*)dres_hi_;
-    const bf16* dres_lo = (const bf16*)dres_lo_;
-    bf16* dx_lo = (bf16*)dx_lo_;
     OCN_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "ocn_layernorm_bwd: bad shape M=%d C=%d", M, C);
     hipStream_t st = (hipStream_t)stream;
     bf16* dx16 = (bf16*)dx_bf16;
     switch (ocn_cdiv(C, 256)) {
-        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo); break;
-        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo); break;
-        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo); break;
-        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo); break;
-        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo); break;
-        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C, dres_hi, dres_lo, dx_lo); break;
+        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
     }
     OCN_CHECK_LAUNCH("ocn_layernorm_bwd");
     return OCN_OK;

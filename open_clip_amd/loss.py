@@ -144,7 +144,8 @@ def _device_scalar(t, dev):
 
 class _ClipLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False, comm=None):
+    def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False, comm=None,
+                logit_bias=None):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         dev = I.device
         s = _device_scalar(logit_scale, dev)  # stays on the device: no host synchronisation inside the step
@@ -213,19 +214,22 @@ class _ClipLossFn(torch.autograd.Function):
                 d_all = None
         acc[1:2].div_(s)  # d loss / d logit_scale = sum(G * logits) / s
         ctx.save_for_backward(dI, dT, acc, d_all)
-        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype, comm)
+        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype, comm, logit_bias is not None)
         return acc[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         dI, dT, acc, d_all = ctx.saved_tensors
-        world_size, B, E, idt, tdt, comm = ctx.meta
+        world_size, B, E, idt, tdt, comm, has_bias = ctx.meta
         if d_all is not None:  # backward of the differentiable all-gather = reduce-scatter(sum) (loss.py:23-26)
             mine = torch.empty(B, 2 * E, dtype=F32, device=dI.device)
             _reduce_scatter_sum(mine, d_all, comm)
             dI = dI + mine[:, :E]
             dT = dT + mine[:, E:]
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None, None
+        # logit_bias shifts every logit of a row alike: its gradient is exactly zero (the softmax gradient of a row sums to 0), but it is
+        # a real gradient, as in the reference (loss.py:111-113) -- DDP then sees the parameter reduced like every other one
+        dbias = (gout * 0.0).reshape(()) if has_bias else None
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None, None, dbias
 
 
 PairTerm = _PairTerm  # the one seam tests replace to exercise the collective plumbing on CPU/gloo
@@ -246,15 +250,15 @@ class NativeClipLoss(nn.Module):
 
     def forward(self, image_features, text_features, logit_scale, logit_bias=None, output_dict=False):
         # loss.py:111-113 adds logit_bias to both logit matrices; a constant added to every logit of a row changes neither the
-        # softmax nor the cross-entropy, so it is accepted and contributes nothing (its gradient is exactly zero there as well)
+        # softmax nor the cross-entropy: the loss ignores its value and hands back the exact (zero) gradient
         loss = _ClipLossFn.apply(image_features, text_features, logit_scale, self.local_loss, self.gather_with_grad,
-                                 self.rank, self.world_size, self.row_sharded, self.comm)
+                                 self.rank, self.world_size, self.row_sharded, self.comm, logit_bias)
         return {"contrastive_loss": loss} if output_dict else loss
 
 
 class _SigLipLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size, comm=None):
+    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size, comm=None, chunk_size=0):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         dev = I.device
         s, b = _device_scalar(logit_scale, dev), _device_scalar(logit_bias, dev)
@@ -267,11 +271,24 @@ class _SigLipLossFn(torch.autograd.Function):
             T_all = T
         # loss.py:406-489: local chunk with positives on the diagonal, every other rank's chunk negative-only.
         # One logits matrix [B, W*B]; the positive diagonal sits at column offset B*rank.
-        term = PairTerm(I, T_all, s).compute_logits(bias=b)
-        term.siglip(B * rank, 0, 1.0 / B, 1.0 / B, acc)
+        if chunk_size and chunk_size < B:
+            # loss.py:369-404 (_chunked_loss): the image rows in chunks of chunk_size against all texts -- peak memory O(chunk_size * N)
+            # for logits and their gradient instead of O(B * N); the positive of chunk row k is column B*rank + i + k.  Same sums, same
+            # gradients (a row's terms never leave its chunk).
+            dI = torch.empty(B, E, dtype=F32, device=dev)
+            dT_all = torch.zeros(T_all.shape[0], E, dtype=F32, device=dev)
+            for i in range(0, B, chunk_size):
+                term = PairTerm(I[i:i + chunk_size], T_all, s).compute_logits(bias=b)
+                term.siglip(B * rank + i, 0, 1.0 / B, 1.0 / B, acc)
+                dI[i:i + chunk_size] = term.dX()
+                dT_all += term.dY()
+                del term
+        else:
+            term = PairTerm(I, T_all, s).compute_logits(bias=b)
+            term.siglip(B * rank, 0, 1.0 / B, 1.0 / B, acc)
+            dI = term.dX()
+            dT_all = term.dY().contiguous()
         acc[1:2].sub_(b * acc[2:3]).div_(s)  # d/dscale = sum(G * (logits - bias)) / s
-        dI = term.dX()
-        dT_all = term.dY().contiguous()
         ctx.save_for_backward(dI, dT_all, acc)
         ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype, comm)
         return acc[0].clone()
@@ -285,13 +302,14 @@ class _SigLipLossFn(torch.autograd.Function):
             _reduce_scatter_sum(dT, dT_all, comm)
         else:
             dT = dT_all
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None, None
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None, None, None
 
 
 class NativeSigLipLoss(nn.Module):
     """``open_clip.loss.SigLipLoss`` (loss.py:314-489).  The W-1 neighbour exchanges of 'bidir'/'shift' are
     replaced by one all-gather of the text features (xGMI is fully connected; the payload is 2 MiB per rank)
-    and one reduce-scatter in the backward -- the loss value and every gradient are identical."""
+    and one reduce-scatter in the backward -- the loss value and every gradient are identical.  ``chunk_size`` > 0 evaluates the image
+    rows in chunks of that many (loss.py:369-404: peak memory O(chunk_size * N) for the logits and their gradient)."""
 
     def __init__(self, cache_labels=False, rank=0, world_size=1, dist_impl=None, chunk_size=0, comm=None):
         super().__init__()
@@ -301,5 +319,5 @@ class NativeSigLipLoss(nn.Module):
         self.chunk_size = chunk_size
 
     def forward(self, image_features, text_features, logit_scale, logit_bias, output_dict=False):
-        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size, self.comm)
+        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size, self.comm, self.chunk_size)
         return {"contrastive_loss": loss} if output_dict else loss

@@ -13,7 +13,6 @@ block by block while the backward is still running, and block-granular recompute
 is a flag of the same Function.
 """
 import math
-import os
 from typing import Optional
 
 import torch
@@ -36,6 +35,7 @@ class _WeightCache:
     def __init__(self):
         self._d = {}
         self.pair_wgrad = True  # block backward: run the wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
+        self.deterministic = False  # weight / bias gradient GEMMs in their reproducible form (ocn_gemm_tn_accum_det)
 
     def get(self, p: torch.Tensor, kind: str):
         """kind: 'n' = bf16 copy [rows, cols]; 't' = bf16 transpose [cols, rows] (2-D views of p)"""
@@ -64,6 +64,13 @@ class _WeightCache:
     def clear(self):
         self._d.clear()
 
+    def __deepcopy__(self, memo):
+        """a copied model (EMA twin, base_task.py:171) has new parameter addresses: none of the cached operand copies could ever hit
+        there, so the copy starts empty instead of duplicating every bf16 weight"""
+        new = _WeightCache()
+        new.pair_wgrad, new.deterministic = self.pair_wgrad, self.deterministic
+        return new
+
 
 # ------------------------------------------------------------------------------------------------------
 # bf16 twins of residual-stream gradients: the kernel that produces a block's input gradient (LayerNorm backward)
@@ -73,33 +80,12 @@ class _WeightCache:
 # version counter): nothing is keyed by address, nothing outlives the tensor, and a consumer that receives any other
 # tensor (autograd summed two branches, a hook replaced the gradient, ...) finds no attribute and casts.
 # ------------------------------------------------------------------------------------------------------
-#
-# OCN_GRAD_STREAM=bf16 (experiment, OFF by default): between the blocks of a tower the bf16 twin IS the gradient -- the LayerNorm
-# backward that ends a block's backward then writes only the bf16 gradient (the next block's GEMM operand AND the residual term its
-# LayerNorm backwards add in: 10 bytes per element instead of 16), and what autograd is handed as the "official" fp32 gradient is a
-# NaN scalar expanded to the right shape (stride 0, no memory); every consumer in this file takes the twin, anything else that touched
-# the placeholder would fail loudly (``_take_twin``) or produce NaN.  Measured on the MI355X (profiles/r02_experiments.txt): -1.7 ms
-# of 233 (the LayerNorm backward is not bandwidth-bound with 8-byte accesses per lane) while 24 residual-gradient additions rounded
-# to bf16 raise the error of the early image blocks' bias / class-embedding gradients from 2e-2 to 4.5-5.4e-2 (above the stated
-# 5e-2) -- so the fp32 stream stays.
 # ------------------------------------------------------------------------------------------------------
 TWIN_STATS = {"hit": 0, "miss": 0}  # how often the hand-off was taken (tests assert it is)
-_BF16_GRAD_STREAM = __import__("os").environ.get("OCN_GRAD_STREAM", "fp32") == "bf16"
 
 
 def _publish_twin(g32, g16):
     g32._ocn_bf16_twin = (g16, g32._version)
-
-
-def _placeholder_grad(g16):
-    """the fp32 'gradient' autograd passes on when the bf16 twin carries the data: NaN, stride 0"""
-    ph = torch.full((1, 1), float("nan"), dtype=F32, device=g16.device).expand(g16.shape)
-    ph._ocn_bf16_twin = (g16, ph._version)
-    return ph
-
-
-def _is_placeholder(g32):
-    return g32.dim() == 2 and g32.stride() == (0, 0) and g32.numel() > 1
 
 
 def _take_twin(g32):
@@ -107,9 +93,6 @@ def _take_twin(g32):
     if tw is not None and tw[1] == g32._version and tw[0].shape == g32.shape and tw[0].device == g32.device:
         TWIN_STATS["hit"] += 1
         return tw[0]
-    if _is_placeholder(g32):
-        raise RuntimeError("open_clip_amd: the bf16 gradient hand-off between blocks was lost (something replaced the gradient tensor "
-                           "autograd carries from one block's backward to the next); set OCN_GRAD_STREAM=fp32")
     TWIN_STATS["miss"] += 1
     return ops.cast_bf16(g32)
 
@@ -125,24 +108,13 @@ def _take_twin(g32):
 # with a fork (side waits for main) before and a join (main waits for side) after every pairing: the persistent NT GEMMs
 # never share the chip with a wgrad (two MFMA-bound kernels only take CUs from each other, and a persistent kernel whose
 # workgroups start late ends late), and the block's gradients are complete on the main stream when they are handed to
-# autograd (DDP hooks / the optimizer run there).  OCN_WGRAD_STREAM=0 keeps everything on one stream.
+# autograd (DDP hooks / the optimizer run there).  ``model.pair_wgrad = False`` keeps everything on one stream.
 # ------------------------------------------------------------------------------------------------------
-import os as _os
-
 _SIDE = {}
-# OCN_LN_PAIR=1 (experiment): hand the residual gradient from LN2's backward to LN1's as a (hi, lo) bf16 pair instead of fp32 +
-# bf16 twin (4 instead of 6 bytes written per element).  Measured 0.6 % SLOWER on the step (two 8-byte accesses per lane instead of
-# one 16-byte one, and the pair cannot use the non-temporal policy of the fp32 copy), so it is off.
-_LN_PAIR = _os.environ.get("OCN_LN_PAIR", "0") == "1"
-# OCN_WGRAD_PAIR (experiment): which HBM-bound kernels get a wgrad GEMM beside them -- "all" (default), "attn" (only the attention
-# backward; the two LayerNorm backwards run alone and their wgrads follow on the main stream), "ln" (only the LayerNorm backwards)
-_PAIR_MODE = _os.environ.get("OCN_WGRAD_PAIR", "all")
 
 
 def _side_stream(dev):
     """the wgrad stream that belongs to the CURRENT stream (one per main stream: the towers may run on streams of their own)"""
-    if _os.environ.get("OCN_WGRAD_STREAM", "1") == "0":
-        return None
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     st = _SIDE.get(key)
     if st is None:
@@ -158,9 +130,6 @@ def _side_stream(dev):
 # wait for the producing node: text-tower nodes (created last, run first in backward) sit on the caller's stream and wait for nothing,
 # the waits for the image tower's blocks queue up behind them.  The per-block wgrad side streams (_Paired) are switched off in this
 # mode (two MFMA-bound streams are enough; measured 191.5 with, 188.1 without).
-# OCN_ATTN_BUCKETS=0: packed text batches launch their attention kernels with every workgroup sized for context_length (A/B knob)
-_ATTN_BUCKETS = _os.environ.get("OCN_ATTN_BUCKETS", "1") != "0"
-_TOWER_STREAMS_DEFAULT = _os.environ.get("OCN_TOWER_STREAMS", "1") != "0"
 _TOWER_SIDE = {}
 
 
@@ -210,6 +179,17 @@ class _Paired:
 # ------------------------------------------------------------------------------------------------------
 # residual block (transformer.py:319-330)
 # ------------------------------------------------------------------------------------------------------
+def _grad_arena(p):
+    """one zeroed fp32 allocation carved into views shaped like the tensors of ``p`` (the wgrad / LayerNorm kernels accumulate into it)"""
+    sizes = [q.numel() for q in p]
+    arena = torch.zeros(sum(sizes), dtype=F32, device=p[0].device)
+    grads, o = [], 0
+    for q, n in zip(p, sizes):
+        grads.append(arena[o:o + n].view(q.shape))
+        o += n
+    return grads
+
+
 def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
     (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
     M, C = x.shape
@@ -252,17 +232,10 @@ class _BlockFn(torch.autograd.Function):
         (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g) = saved
         M, C = x.shape
         Fd = wfc.shape[0]
-        dy16 = _take_twin(dy)  # before anything touches dy: between blocks it is a stride-0 placeholder and the twin is the gradient
-        stream16 = _BF16_GRAD_STREAM and not _LN_PAIR
-        if not stream16:
-            dy = dy.contiguous() if not _is_placeholder(dy) else dy16.float()
+        dy16 = _take_twin(dy)
+        dy = dy.contiguous()
         # one zeroed fp32 arena for all of the block's parameter gradients (wgrad kernels accumulate atomically)
-        sizes = [q.numel() for q in p]
-        arena = torch.zeros(sum(sizes), dtype=F32, device=x.device)
-        grads, o = [], 0
-        for q, n in zip(p, sizes):
-            grads.append(arena[o:o + n].view(q.shape))
-            o += n
+        grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
 
         dev = x.device
@@ -273,37 +246,26 @@ class _BlockFn(torch.autograd.Function):
         # ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(ln_2(x_mid)))) ----
         df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
         dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
-        pair = cache.pair_wgrad
-        with _Paired(dev, pair and _PAIR_MODE in ("all", "ln")) as side:
+        pair, det = cache.pair_wgrad, cache.deterministic
+        with _Paired(dev, pair) as side:
             if need_w:
-                side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj)
-            # dxmid leaves as a (hi, lo) bf16 pair: hi is the operand of the next two GEMMs, hi + lo the residual gradient that the
-            # LayerNorm backward below adds in (4 bytes per element instead of fp32 + bf16 twin = 6)
-            if _LN_PAIR:
-                _, dxmid16, dxmid_lo = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_pair=True)
-            elif stream16:  # residual gradient in and out in bf16 only
-                _, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres16=dy16, want_f32=False, want_bf16=True)
-            else:
-                dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
+                side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj, 1.0, det)
+            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, pair and _PAIR_MODE in ("all", "attn")) as side:
+        with _Paired(dev, pair) as side:
             if need_w:
-                side(ops.gemm_tn_accum, df, h2, dwfc, dbfc)
+                side(ops.gemm_tn_accum, df, h2, dwfc, dbfc, 1.0, det)
             dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, pair and _PAIR_MODE in ("all", "ln")) as side:
-            if need_w:  # out-proj and QKV wgrads share their rows and their K = C: one launch (36 tiles, 7 M-splits instead of 28 + 9)
+        with _Paired(dev, pair) as side:
+            if need_w and det:
+                side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo, 1.0, True)
+                side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv, 1.0, True)
+            elif need_w:  # out-proj and QKV wgrads share their rows and their K = C: one launch (36 tiles, 7 M-splits instead of 28 + 9)
                 side(ops.gemm_tn_accum2, dxmid16, a, dwo, dbo, dqkv, h1, dwqkv, dbqkv)
-            if _LN_PAIR:
-                dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres_pair=(dxmid16, dxmid_lo), want_f32=True, want_bf16=True)
-            elif stream16:
-                _, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres16=dxmid16, want_f32=False, want_bf16=True)
-                dx = _placeholder_grad(dx16)
-            else:
-                dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True)
-        if not stream16 or _LN_PAIR:
-            _publish_twin(dx, dx16)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True)
+        _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None)
@@ -316,12 +278,9 @@ class _BlockFn(torch.autograd.Function):
 # i reads the K / V of the other rows).  So of the last block only  LN1 -> QKV -> attention  has to run on every row; the out-projection,
 # both residual adds, LN2 and the whole MLP are needed on the B pooled rows alone (1 row in 50 / 43), forward and backward: the rows that
 # are dropped reach neither the features nor any gradient.  Same results as the full block up to fp32 summation order
-# (tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); ``model.pooled_last_block = False`` / OCN_POOLED_LAST_BLOCK=0 runs
+# (tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); ``model.pooled_last_block = False`` (a constructor argument, too) runs
 # the full block.  `rows` = absolute row of each sequence's pooled token (int32 [B]); the output is [B, C].
 # ------------------------------------------------------------------------------------------------------
-_POOLED_LAST_BLOCK = _os.environ.get("OCN_POOLED_LAST_BLOCK", "1") != "0"
-
-
 def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None):
     (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
     M, C = x.shape
@@ -365,12 +324,7 @@ class _PooledBlockFn(torch.autograd.Function):
         Fd = wfc.shape[0]
         dy16 = _take_twin(dy_p)
         dy_p = dy_p.contiguous()
-        sizes = [q.numel() for q in p]
-        arena = torch.zeros(sum(sizes), dtype=F32, device=x.device)
-        grads, o = [], 0
-        for q, n in zip(p, sizes):
-            grads.append(arena[o:o + n].view(q.shape))
-            o += n
+        grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
         need_w = any(ctx.needs_input_grad[1:13])
         # ---- MLP branch and out-projection: the B pooled rows ----
@@ -378,17 +332,18 @@ class _PooledBlockFn(torch.autograd.Function):
         dh2_p = ops.gemm_nt(ops.EPI_BF16, df_p, cache.get(wfc, "t"), ops.empty((B, C), BF16, x))
         dxmid_p, dxmid16_p = ops.layernorm_bwd(dh2_p, xmid_p, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy_p, want_f32=True, want_bf16=True)
         da_p = ops.gemm_nt(ops.EPI_F32, dxmid16_p, cache.get(wo, "t"), ops.empty((B, C), F32, x))
+        det = cache.deterministic
         if need_w:
-            ops.gemm_tn_accum(dy16, g_p, dwproj, dbproj)
-            ops.gemm_tn_accum(df_p, h2_p, dwfc, dbfc)
-            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, dbo)
+            ops.gemm_tn_accum(dy16, g_p, dwproj, dbproj, 1.0, det)
+            ops.gemm_tn_accum(df_p, h2_p, dwfc, dbfc, 1.0, det)
+            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, dbo, 1.0, det)
         # ---- attention and everything below it: every row (the pooled rows' queries read all keys / values) ----
         da = torch.zeros((M, C), dtype=BF16, device=x.device)
         ops.scatter_rows(da_p, rows, None, B, 0, da)
         dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
         if need_w:
-            ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv)
+            ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv, 1.0, det)
         dres = torch.zeros((M, C), dtype=F32, device=x.device)  # the residual path x -> xmid carries gradient on the pooled rows only
         ops.scatter_rows(dxmid_p, rows, dres, B, 0, None)
         dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True)
@@ -426,6 +381,7 @@ class _VisionEmbedFn(torch.autograd.Function):
         _, x0, mean, rstd = ops.layernorm_fwd(emb, lnw, lnb, want_bf16=False, want_f32=True)
         ctx.save_for_backward(patches, emb, mean, rstd, lnw, conv_w, cls, pos)
         ctx.meta = (B, G, width, KP, Kpad)
+        ctx.cache = cache
         return x0
 
     @staticmethod
@@ -434,12 +390,12 @@ class _VisionEmbedFn(torch.autograd.Function):
         B, G, width, KP, Kpad = ctx.meta
         dev = emb.device
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
-        dy0 = _take_twin(dx0) if _is_placeholder(dx0) else dx0.contiguous()  # the bf16 gradient stream of the blocks ends here
+        dy0 = dx0.contiguous()
         demb, _ = ops.layernorm_bwd(dy0, emb, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
         dpos, dcls = torch.zeros_like(pos), torch.zeros_like(cls)
         dpatch = ops.embed_assemble_bwd(demb, dpos, dcls, B, G, width)
         dw = torch.zeros(width, Kpad, dtype=F32, device=dev)
-        ops.gemm_tn_accum(dpatch, patches, dw)
+        ops.gemm_tn_accum(dpatch, patches, dw, None, 1.0, ctx.cache.deterministic)
         dconv = (dw if Kpad == KP else dw[:, :KP].contiguous()).view(conv_w.shape)
         return None, dconv, dcls, dpos, dlnw, dlnb, None, None, None
 
@@ -462,7 +418,7 @@ class _TextEmbedFn(torch.autograd.Function):
     def backward(ctx, dx):
         text, table, pos = ctx.saved_tensors
         dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
-        dxv = _take_twin(dx) if _is_placeholder(dx) else dx.contiguous()  # bf16 when the blocks hand their gradient over in bf16
+        dxv = dx.contiguous()
         if ctx.pack is None:
             ops.token_embed_bwd_sorted(text.contiguous(), dxv, dtable, dpos)
         else:
@@ -480,13 +436,13 @@ class _TextPack:
     waits for that copy (the only host synchronisation of the step; it is issued BEFORE the image tower so that it never drains
     the queue) and builds the packed token / position lists."""
 
-    def __init__(self, text, vocab_size=None):
+    def __init__(self, text, vocab_size=None, buckets=True):
         self.text = text = text.contiguous()
         self.B, self.L = text.shape
         self.vocab_size = vocab_size
         # with the vocabulary size the plan also counts ids outside [0, vocab): the embedding kernels clamp them (they can never read
         # outside the table), nn.Embedding raises (model.py:399) -- so does finish(), from the same 8-byte read-back
-        self.eot, plan, self.last_row, self.order = ops.seq_pack_plan(text, vocab_size, buckets=_ATTN_BUCKETS)
+        self.eot, plan, self.last_row, self.order = ops.seq_pack_plan(text, vocab_size, buckets=buckets)
         self.seq_off = self.layout = plan[:self.B + 1]
         self._m_host = torch.empty(plan.numel() - self.B, dtype=torch.int32).pin_memory()  # [M, ids out of range, bucket counts ...]
         self._m_host.copy_(plan[self.B:], non_blocking=True)
@@ -536,7 +492,7 @@ class _HeadFn(torch.autograd.Function):
         C, E = proj.shape
         dp16 = ops.gemm_nt(ops.EPI_BF16, dfeat16, cache.get(proj, "n"), ops.empty((B, C), BF16, dy))
         dproj = torch.zeros_like(proj)
-        ops.gemm_tn_accum(p16, dfeat16, dproj)
+        ops.gemm_tn_accum(p16, dfeat16, dproj, None, 1.0, cache.deterministic)
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
         dpooled, _ = ops.layernorm_bwd(dp16, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
         dx = torch.zeros(xshape, dtype=F32, device=dy.device)
@@ -609,7 +565,12 @@ class ResidualAttentionBlock(nn.Module):  # transformer.py:274-330
     def get_weight_dtype(self):
         return self.mlp.c_fc.weight.dtype
 
-    def forward(self, x, cache, B, L, causal, recompute=False, seq_off=None):
+    def forward(self, x, cache, B, L, causal, recompute=False, seq_off=None, pooled_rows=None):
+        """``pooled_rows`` (int32 [B], absolute rows): the caller reads only these rows of the output -- everything behind the attention
+        then runs on them alone and the result is [B, C] (_PooledBlockFn).  Both forms go through ``Module.__call__``, so forward /
+        forward-pre hooks on the block (FSDP2's unshard, feature extraction, profilers) fire either way."""
+        if pooled_rows is not None:
+            return _PooledBlockFn.apply(x, *self.params(), pooled_rows, cache, B, L, self.n_head, causal, recompute, seq_off)
         return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute, seq_off)
 
 
@@ -635,13 +596,13 @@ class Transformer(nn.Module):  # transformer.py:476-585
         for r in blocks:
             x = r(x, cache, B, L, causal, rc, seq_off)
         if last is not None:
-            x = _PooledBlockFn.apply(x, *last.params(), pooled_rows, cache, B, L, last.n_head, causal, rc, seq_off)
+            x = last(x, cache, B, L, causal, rc, seq_off, pooled_rows)
         return x
 
 
 def _pooled_last_block_ok(module) -> bool:
-    """the pooled form of the last block (see _PooledBlockFn) unless switched off on the module or by one of the gradient-stream experiments"""
-    return getattr(module, "pooled_last_block", True) and _POOLED_LAST_BLOCK and not _BF16_GRAD_STREAM and not _LN_PAIR
+    """the pooled form of the last block (see _PooledBlockFn) unless switched off on the module"""
+    return bool(getattr(module, "pooled_last_block", True))
 
 
 def _set_group_requires_grad(members, requires_grad: bool):  # transformer.py:2034-2041
@@ -777,7 +738,17 @@ class NativeCLIP(nn.Module):
                                           f"(supported: {sorted(ok)}; everything else only at the reference default)")
 
     def __init__(self, embed_dim, vision_cfg, text_cfg, init_logit_scale=math.log(1 / 0.07), init_logit_bias=None,
-                 output_dict=False, **model_kwargs):
+                 output_dict=False, *, pack_text=True, tower_streams=True, pooled_last_block=True, attn_buckets=True, pair_wgrad=True,
+                 deterministic=False, **model_kwargs):
+        """Reference arguments first (model.py:318-365).  Keyword-only switches of the native execution (every one also a plain attribute
+        that may be flipped later; none changes a result beyond fp32 summation order):
+        ``pack_text`` -- the text tower holds only the tokens up to the pooled EOT (_TextPack); ``tower_streams`` -- image tower on a
+        stream of its own next to the text tower; ``pooled_last_block`` -- the last block of each tower behind its attention on the
+        pooled rows only (_PooledBlockFn; ``model.visual.pooled_last_block`` is the image tower's switch); ``attn_buckets`` -- packed
+        attention launches grouped by 32-row block count; ``pair_wgrad`` -- in one-stream mode, the blocks' wgrad GEMMs on a side
+        stream under the HBM-bound kernels; ``deterministic`` -- every weight / bias gradient GEMM in its reproducible form (per-split
+        slabs summed in a fixed order instead of fp32 atomics: 98 % of the gradient elements; the LayerNorm-affine, embedding and
+        scalar-loss reductions still accumulate with fp32 atomics)."""
         super().__init__()
         v, t = dict(vision_cfg), dict(text_cfg)
         self._check_cfg(v, t, model_kwargs)
@@ -805,15 +776,17 @@ class NativeCLIP(nn.Module):
         self.logit_bias = nn.Parameter(torch.ones([]) * init_logit_bias) if init_logit_bias is not None else None
         self._cache = _WeightCache()
         # packed text tower (see _TextPack): on by default where the varlen attention kernels apply (head_dim 64, L <= 320);
-        # ``model.pack_text = False`` (or OCN_TEXT_PACK=0) runs every one of the context_length positions like the reference does
-        self.pack_text = (os.environ.get("OCN_TEXT_PACK", "1") != "0" and t["width"] // t["heads"] == 64 and self.context_length <= 320)
+        # ``pack_text = False`` runs every one of the context_length positions like the reference does
+        self.pack_text = bool(pack_text) and t["width"] // t["heads"] == 64 and self.context_length <= 320
+        self.attn_buckets = bool(attn_buckets)
         # True: image tower on a stream of its own next to the text tower (see _TOWER_SIDE); False: one stream; "serial": the same two
         # streams, one tower at a time (bench.py's event-timed steps)
-        self.tower_streams = _TOWER_STREAMS_DEFAULT
+        self.tower_streams = tower_streams
         # the last block of each tower only where its output is read (see _PooledBlockFn); the image tower has its own switch
         # (``model.visual.pooled_last_block``)
-        self.pooled_last_block = True
-        self.pair_wgrad = True  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
+        self.pooled_last_block = self.visual.pooled_last_block = bool(pooled_last_block)
+        self.deterministic = bool(deterministic)
+        self.pair_wgrad = bool(pair_wgrad)  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
         # manual re-initialisation) do not move the counter, so every load_state_dict drops them
@@ -870,15 +843,22 @@ class NativeCLIP(nn.Module):
     def no_weight_decay(self):
         return {"positional_embedding"} | {"visual." + n for n in self.visual.no_weight_decay()}
 
+    def _sync_options(self, overlap=False):
+        """execution switches of the model onto the two towers' operand caches (which the autograd Functions carry)"""
+        self._cache.pair_wgrad = self.visual._cache.pair_wgrad = self.pair_wgrad and not overlap
+        self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
+
     def encode_image(self, image, normalize: bool = False):
+        self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
         return self.visual(image, normalize)
 
     def encode_text(self, text, normalize: bool = False, _pack=None):
         B, L = text.shape
         if L != self.context_length:
             raise RuntimeError(f"text length {L} != context_length {self.context_length}")
+        self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
         if self.pack_text:
-            pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size)).finish()
+            pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size, self.attn_buckets)).finish()
             x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)
             if _pooled_last_block_ok(self):
                 x = self.transformer(x, self._cache, B, L, True, pack.layout, pack.last_row)  # [B, C]: the EOT rows
@@ -887,6 +867,9 @@ class NativeCLIP(nn.Module):
             x = self.transformer(x, self._cache, B, L, True, pack.layout)
             # L = 0: last_row holds absolute rows of the packed matrix
             return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, pack.last_row, self._cache, B, 0, normalize)
+        # ids outside the vocabulary raise like nn.Embedding (model.py:399); the packed path gets the count with its plan's read-back
+        if int(ops.token_range_check(text.contiguous(), self.vocab_size)) != 0:
+            raise IndexError(f"index out of range in self: token id(s) outside [0, {self.vocab_size}) (token_embedding has {self.vocab_size} rows)")
         x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
         idx = ops.argmax_rows(text.contiguous())
         if _pooled_last_block_ok(self):
@@ -905,9 +888,9 @@ class NativeCLIP(nn.Module):
 
     def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):
         # the packed text layout is planned first: its 4-byte read-back then completes while the image tower is being enqueued
-        pack = _TextPack(text, self.vocab_size) if (text is not None and self.pack_text) else None
+        pack = _TextPack(text, self.vocab_size, self.attn_buckets) if (text is not None and self.pack_text) else None
         overlap = self.tower_streams and image is not None and text is not None
-        self._cache.pair_wgrad = self.visual._cache.pair_wgrad = self.pair_wgrad and not overlap
+        self._sync_options(overlap)
         if overlap:
             dev = text.device
             cur = torch.cuda.current_stream(dev)
@@ -987,12 +970,17 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     for k in cfg:
         if k not in ("embed_dim", "vision_cfg", "text_cfg"):
             extra_model_kwargs.setdefault(k, cfg[k])
-    kw = {}
+    # a registered config may carry init_logit_scale / init_logit_bias / output_dict itself (the reference's SigLIP JSONs do); the explicit
+    # argument wins over the config's value, as in the reference (factory.py:547-556)
+    kw = {k: extra_model_kwargs.pop(k) for k in ("init_logit_scale", "init_logit_bias") if k in extra_model_kwargs}
+    cfg_output_dict = extra_model_kwargs.pop("output_dict", None)
     if init_logit_scale is not None:
         kw["init_logit_scale"] = init_logit_scale
     if init_logit_bias is not None:
         kw["init_logit_bias"] = init_logit_bias
-    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=bool(output_dict), **kw, **extra_model_kwargs)
+    kw = {k: v for k, v in kw.items() if v is not None}
+    out_dict = output_dict if output_dict is not None else cfg_output_dict
+    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=bool(out_dict), **kw, **extra_model_kwargs)
     if pretrained:
         sd = torch.load(pretrained, map_location="cpu", weights_only=True)
         sd = sd.get("state_dict", sd)

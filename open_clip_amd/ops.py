@@ -62,8 +62,9 @@ def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
     return out
 
 
-def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0):
-    """dw[N,K] += alpha * a[M,N]^T @ b[M,K]; dbias[N] += alpha * colsum(a).  a, b bf16; dw, dbias fp32."""
+def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0, deterministic=False):
+    """dw[N,K] += alpha * a[M,N]^T @ b[M,K]; dbias[N] += alpha * colsum(a).  a, b bf16; dw, dbias fp32.
+    ``deterministic``: the reproducible form (ocn_gemm_tn_accum_det: per-split slabs summed in a fixed order instead of fp32 atomics)"""
     pa, lda = _chk2d(a, BF16, "a")
     pb, ldb = _chk2d(b, BF16, "b")
     pw, ldw = _chk2d(dw, F32, "dw")
@@ -71,10 +72,13 @@ def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0):
     K = b.shape[1]
     if b.shape[0] != M or dw.shape[0] != N or dw.shape[1] != K:
         raise RuntimeError(f"gemm_tn_accum: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} dw{tuple(dw.shape)}")
-    need = _lib.load().ocn_gemm_tn_workspace_bytes(M, N, K)  # > 0: partial tiles + reduce instead of contended atomics
-    ws = torch.empty(need, dtype=torch.uint8, device=a.device) if need > 0 else None
-    _lib.call("ocn_gemm_tn_accum_ws", pa, lda, pb, ldb, pw, ldw, M, N, K, _chk(dbias, F32, "dbias"), float(alpha),
-              0 if ws is None else ws.data_ptr(), need, _stream())
+    if deterministic:
+        need = _lib.load().ocn_gemm_tn_det_workspace_bytes(M, N, K)
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device) if need > 0 else None
+        _lib.call("ocn_gemm_tn_accum_det", pa, lda, pb, ldb, pw, ldw, M, N, K, _chk(dbias, F32, "dbias"), float(alpha),
+                  0 if ws is None else ws.data_ptr(), need, _stream())
+        return dw
+    _lib.call("ocn_gemm_tn_accum", pa, lda, pb, ldb, pw, ldw, M, N, K, _chk(dbias, F32, "dbias"), float(alpha), _stream())
     return dw
 
 
@@ -130,23 +134,15 @@ def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dres_pair=None, want_pair=False, dres16=None):
-    """``dres16`` = the residual gradient in bf16 (instead of an fp32 ``dres``); ``dres_pair`` = (hi, lo) bf16 tensors;
-    ``want_pair`` returns (None, hi, lo) instead of (dx32, dx16): the residual gradient as a bf16 pair (see ocn_layernorm_bwd_pair)."""
-    if dres16 is not None:
-        dres_pair = (dres16, None)
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False):
+    """(dx fp32 | None, dx bf16 | None); ``dres`` = the residual branch's fp32 gradient, added in; dw / db are accumulated into"""
     M, C = x.shape
     is32 = dy.dtype == F32
-    dx32 = empty((M, C), F32, x) if (want_f32 and not want_pair) else None
-    dx16 = empty((M, C), BF16, x) if (want_bf16 or want_pair) else None
-    dxlo = empty((M, C), BF16, x) if want_pair else None
-    hi, lo = dres_pair if dres_pair is not None else (None, None)
-    _lib.call("ocn_layernorm_bwd_pair", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
-              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(hi, BF16, "dres_hi"), _chk(lo, BF16, "dres_lo"),
-              _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"), _chk(dxlo, BF16, "dx_lo"), _chk(dw, F32, "dw"), _chk(db, F32, "db"), M, C,
-              _stream())
-    if want_pair:
-        return None, dx16, dxlo
+    dx32 = empty((M, C), F32, x) if want_f32 else None
+    dx16 = empty((M, C), BF16, x) if want_bf16 else None
+    _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
+              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"),
+              _chk(dw, F32, "dw"), _chk(db, F32, "db"), M, C, _stream())
     return dx32, dx16
 
 

@@ -163,6 +163,27 @@ def _dist_worker(rank, world, port, q):
     res["siglip/bidir/dtxt"] = txt.grad.numpy()
     res["siglip/bidir/dscale"] = s.grad.numpy()
     res["siglip/bidir/dbias"] = b.grad.numpy()
+    # the memory-efficient chunked evaluation (loss.py:369-404) and ClipLoss with a logit_bias (loss.py:111-113: real, zero gradient)
+    img = feats[rank, 0].clone().requires_grad_(True)
+    txt = feats[rank, 1].clone().requires_grad_(True)
+    s = scale.clone().requires_grad_(True)
+    b = bias.clone().requires_grad_(True)
+    loss = SigLipLoss(rank=rank, world_size=world, dist_impl="bidir", chunk_size=2)(img, txt, s, b)
+    loss.backward()
+    res["siglip/chunked/loss"] = loss.detach().numpy()
+    res["siglip/chunked/dimg"] = img.grad.numpy()
+    res["siglip/chunked/dtxt"] = txt.grad.numpy()
+    res["siglip/chunked/dscale"] = s.grad.numpy()
+    res["siglip/chunked/dbias"] = b.grad.numpy()
+    img = feats[rank, 0].clone().requires_grad_(True)
+    txt = feats[rank, 1].clone().requires_grad_(True)
+    s = scale.clone().requires_grad_(True)
+    b = bias.clone().requires_grad_(True)
+    loss = ClipLoss(rank=rank, world_size=world, local_loss=True, gather_with_grad=True)(img, txt, s, b)
+    loss.backward()
+    res["clip/local_gwg_bias/loss"] = loss.detach().numpy()
+    res["clip/local_gwg_bias/dimg"] = img.grad.numpy()
+    res["clip/local_gwg_bias/dbias"] = b.grad.numpy()
     q.put((rank, res, feats.numpy() if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
@@ -201,5 +222,6 @@ if __name__ == "__main__":
     if "dist" in which:
         make_dist(2, 29611)
         make_dist(3, 29612)
+        make_dist(8, 29613)  # the 8-rank world of BASELINE config 3
     if "vitb32" in which:
         make_vitb32()

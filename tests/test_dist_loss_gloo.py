@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 3 over gloo: the collective plumbing of NativeClipLoss / NativeSigLipLoss
+"""CPU, world_size 2, 3 and 8 over gloo: the collective plumbing of NativeClipLoss / NativeSigLipLoss
 (packed all-gather, which operands carry gradient per mode, reduce-scatter backward) reproduces the per-rank
 losses and gradients the REFERENCE produced (tests/golden/dist_loss_w*.npz).
 
@@ -80,19 +80,34 @@ def _worker(rank, world, port, q):
     loss = L.NativeSigLipLoss(rank=rank, world_size=world)(img, txt, s, b)
     loss.backward()
     res["siglip"] = (float(loss), img.grad.numpy(), txt.grad.numpy(), float(s.grad), float(b.grad))
+    # SigLipLoss(chunk_size=2) (loss.py:369-404) and ClipLoss with a logit_bias (loss.py:111-113: a real, exactly zero gradient)
+    img = feats[rank, 0].clone().requires_grad_(True)
+    txt = feats[rank, 1].clone().requires_grad_(True)
+    s = torch.tensor(float(g["scale"]), requires_grad=True)
+    b = torch.tensor(float(g["bias"]), requires_grad=True)
+    loss = L.NativeSigLipLoss(rank=rank, world_size=world, chunk_size=2)(img, txt, s, b)
+    loss.backward()
+    res["siglip_chunked"] = (float(loss), img.grad.numpy(), txt.grad.numpy(), float(s.grad), float(b.grad))
+    img = feats[rank, 0].clone().requires_grad_(True)
+    txt = feats[rank, 1].clone().requires_grad_(True)
+    s = torch.tensor(float(g["scale"]), requires_grad=True)
+    b = torch.tensor(float(g["bias"]), requires_grad=True)
+    loss = L.NativeClipLoss(rank=rank, world_size=world, local_loss=True, gather_with_grad=True)(img, txt, s, b)
+    loss.backward()
+    res["clip_bias"] = (float(loss), img.grad.numpy(), None if b.grad is None else float(b.grad))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,port", [(2, 29721), (3, 29722)])
+@pytest.mark.parametrize("world,port", [(2, 29721), (3, 29722), (8, 29723)])
 def test_native_losses_reproduce_reference_collective_semantics(world, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=240) for _ in range(world))
+    got = dict(q.get(timeout=400) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
     g = load(f"dist_loss_w{world}.npz")
@@ -111,9 +126,14 @@ def test_native_losses_reproduce_reference_collective_semantics(world, port):
         np.testing.assert_allclose(di, g[pre + "dimg"], atol=2e-6, err_msg="rowsharded " + pre)
         np.testing.assert_allclose(dt, g[pre + "dtxt"], atol=2e-6, err_msg="rowsharded " + pre)
         assert abs(ds - float(g[pre + "dscale"])) < 1e-5
-        loss, di, dt, ds, db = got[rank]["siglip"]
-        pre = f"r{rank}/siglip/bidir/"
+        for key, pre in (("siglip", f"r{rank}/siglip/bidir/"), ("siglip_chunked", f"r{rank}/siglip/chunked/")):
+            loss, di, dt, ds, db = got[rank][key]
+            assert abs(loss - float(g[pre + "loss"])) < 1e-5, pre
+            np.testing.assert_allclose(di, g[pre + "dimg"], atol=2e-6, err_msg=pre)
+            np.testing.assert_allclose(dt, g[pre + "dtxt"], atol=2e-6, err_msg=pre)
+            assert abs(ds - float(g[pre + "dscale"])) < 2e-5 and abs(db - float(g[pre + "dbias"])) < 2e-5, pre
+        loss, di, db = got[rank]["clip_bias"]
+        pre = f"r{rank}/clip/local_gwg_bias/"
         assert abs(loss - float(g[pre + "loss"])) < 1e-5
-        np.testing.assert_allclose(di, g[pre + "dimg"], atol=2e-6)
-        np.testing.assert_allclose(dt, g[pre + "dtxt"], atol=2e-6)
-        assert abs(ds - float(g[pre + "dscale"])) < 1e-5 and abs(db - float(g[pre + "dbias"])) < 1e-5
+        np.testing.assert_allclose(di, g[pre + "dimg"], atol=2e-6, err_msg=pre)
+        assert db is not None and abs(db - float(g[pre + "dbias"])) < 1e-6, "ClipLoss must hand logit_bias a (zero) gradient, as the reference does"

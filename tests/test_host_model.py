@@ -208,3 +208,66 @@ def test_load_state_dict_drops_the_cached_operand_copies():
     m.visual._cache._d[("y", "n")] = (0, (1,), None)
     m.load_state_dict(m.state_dict())
     assert not m._cache._d and not m.visual._cache._d
+
+
+def test_execution_switches_are_constructor_arguments_and_copies_start_with_empty_caches():
+    """the switches of the native execution are keyword arguments / attributes (no environment variables are read); a deep copy of the
+    model (the EMA twin of base_task.py:171) does not duplicate the cached bf16 operand copies"""
+    import copy
+    import inspect
+    import open_clip_amd.model as M
+    assert "environ" not in inspect.getsource(M), "model.py must not read environment switches"
+    cfg = get_model_config("tiny-test")
+    m = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], pack_text=False, tower_streams=False, pooled_last_block=False,
+                   attn_buckets=False, pair_wgrad=False, deterministic=True)
+    assert (m.pack_text, m.tower_streams, m.pooled_last_block, m.visual.pooled_last_block, m.attn_buckets, m.pair_wgrad, m.deterministic) == \
+        (False, False, False, False, False, False, True)
+    d = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"])
+    assert (d.pack_text, d.tower_streams, d.pooled_last_block, d.visual.pooled_last_block, d.attn_buckets, d.pair_wgrad, d.deterministic) == \
+        (True, True, True, True, True, True, False)
+    d._cache._d[("x", "n")] = (0, (1,), torch.zeros(3))
+    d.visual._cache.deterministic = True
+    twin = copy.deepcopy(d)
+    assert twin._cache._d == {} and twin.visual._cache._d == {} and twin.visual._cache.deterministic is True
+    assert ("x", "n") in d._cache._d  # the original keeps its copies
+
+
+def test_create_model_explicit_arguments_win_over_config_values():
+    """a registered config may carry init_logit_scale / init_logit_bias / output_dict itself (the reference's SigLIP JSONs do): the explicit
+    create_model argument overrides it, as in the reference (factory.py:547-556), instead of a duplicate-keyword TypeError"""
+    import math
+    from open_clip_amd.configs import add_model_config
+    cfg = get_model_config("tiny-test")
+    cfg = dict(cfg, init_logit_bias=-10.0, init_logit_scale=math.log(10), output_dict=True)
+    add_model_config("tiny-siglip-cfg", cfg)
+    m = create_model("tiny-siglip-cfg", device="meta")
+    assert m.logit_bias is not None and m.output_dict is True
+    m = create_model("tiny-siglip-cfg", device="meta", init_logit_bias=-3.0, init_logit_scale=1.5, output_dict=False)
+    assert m.output_dict is False and m.logit_bias is not None
+
+
+def test_last_block_hooks_fire_in_the_pooled_form(monkeypatch):
+    """the pooled form of the last block goes through Module.__call__ (FSDP2's unshard / user hooks sit there); the kernels are replaced
+    by stand-ins here, only the module plumbing is under test"""
+    import open_clip_amd.model as M
+
+    class FakeBlock:
+        @staticmethod
+        def apply(x, *a):
+            return x
+
+    class FakePooled:
+        @staticmethod
+        def apply(x, *a):
+            rows = a[12]
+            return x[rows.long()]
+
+    monkeypatch.setattr(M, "_BlockFn", FakeBlock)
+    monkeypatch.setattr(M, "_PooledBlockFn", FakePooled)
+    t = M.Transformer(64, 3, 1)
+    fired = []
+    t.resblocks[-1].register_forward_pre_hook(lambda mod, args: fired.append("pre"))
+    t.resblocks[-1].register_forward_hook(lambda mod, args, out: fired.append("post"))
+    x = torch.randn(10, 64)
+    y = t(x, None, 2, 5, False, None, torch.tensor([0, 5], dtype=torch.int32))
+    assert fired == ["pre", "post"] and y.shape == (2, 64)

@@ -125,11 +125,9 @@ def tn_sweep():
             ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
             row.append(f"{'no-epilogue' if ab else 'full'} {ms:.3f} ms ({2.0 * M * N * K / ms / 1e9:5.0f} TF/s)")
         _lib.call("ocn_set_tuning", 4, 0)
-        for k in (0, 2, 0, 2):  # developer knob 12 = 2: partial tiles into a workspace + reduce pass instead of atomics
-            _lib.call("ocn_set_tuning", 12, k)
-            ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db))
-            row.append(f"{'two-stage' if k else 'atomics'} {ms:.3f} ms")
-        _lib.call("ocn_set_tuning", 12, 0)
+        for det in (False, True, False, True):  # the reproducible form: per-split slabs + an ordered reduce pass instead of atomics
+            ms = timeit(lambda: ops.gemm_tn_accum(a, b, dw, db, deterministic=det))
+            row.append(f"{'deterministic' if det else 'atomics'} {ms:.3f} ms")
         print(f"tn {name:9s} dW[{N},{K}]: " + " | ".join(row), flush=True)
         del a, b
 
