@@ -21,6 +21,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_SPEC_GBPS, HBM_ACHIEVABLE_GBPS = 8000.0, 6300.0  # MI355X_MICROARCH.md: 8 TB/s spec, 6.29 TB/s measured with a float4 copy
+
+
+def code_identity():
+    """(git sha of the tree or None, sha256[:16] over the kernel sources): the second is what profiles/pmc_traffic.json is compared with --
+    a PMC figure taken on other kernel code is marked stale on the line"""
+    import hashlib
+    import subprocess
+    sha = None
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        sha = None
+    if sha is None and os.path.exists(os.path.join(ROOT, ".head_sha")):
+        sha = open(os.path.join(ROOT, ".head_sha")).read().strip() or None
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "open_clip_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return sha, h.hexdigest()[:16]
 FWD_GFLOP_PER_PAIR = {"ViT-B-32": 14.78, "ViT-L-14": 175.33, "ViT-H-14": 381.68}  # docs/model_profile.csv (reference)
 
 
@@ -33,7 +55,8 @@ def parse():
     ap.add_argument("--local-batch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the plain PyTorch-ROCm eager step timed beside the native one (N=1)")
-    ap.add_argument("--eager-batch", type=int, default=1024, help="batch of the eager baseline (bounded: eager autograd keeps ~2x the activations)")
+    ap.add_argument("--eager-batch", type=int, default=4096, help="batch of the eager baseline (the bench's own batch: like for like; halved on out-of-memory)")
+    ap.add_argument("--deterministic", action="store_true", help="weight / bias gradient GEMMs in their reproducible form (NativeCLIP(deterministic=True))")
     ap.add_argument("--accum-freq", type=int, default=1, help="reference --accum-freq semantics (train.py:236-311): F micro-batches of "
                     "--local-batch per optimizer step (features cached under no_grad, every micro-batch re-run with gradient against the "
                     "concatenation) -> global batch = local_batch * F * N; --accum-freq 8 is the metric's gbs=32768 on ONE GPU")
@@ -65,15 +88,17 @@ def parse():
     return ap.parse_args()
 
 
-NT_KERNEL = {0: "gemm_nt5_kernel<0,false,0> (plain bf16 out)", 1: "gemm_nt5_kernel<1,false,2> (bias + GELU, saves gelu')",
-             2: "gemm_nt5_kernel<2,false,40> (bias + fp32 residual)", 3: "gemm_nt5_kernel<3,false,32> (x saved gelu')",
+NT_KERNEL = {0: "gemm_nt5_kernel<0,false,0> (plain bf16 out)", 1: "gemm_nt5_kernel<1,false,2> (bias + GELU, saves gelu' in 8 bits)",
+             2: "gemm_nt5_kernel<2,false,40> (bias + fp32 residual)", 3: "gemm_nt5_kernel<3,false,32> (x saved 8-bit gelu')",
              4: "gemm_nt5_kernel<4,false,0> (fp32 out)", 5: "gemm_nt5_kernel<5,false,0> (logits: CE statistics)",
              6: "gemm_nt5_kernel<6,false,0> (logits: CE gradient)"}
 
 
 class GemmTimer:
     """HIP events around every ocn_gemm_nt / ocn_gemm_tn_accum launch (same stream as the launch), grouped by kernel instantiation
-    (the names rocprofv3 shows: the NT kernel's epilogue / cache-policy template arguments, the TN kernel with / without bias row)."""
+    (the names rocprofv3 shows: the NT kernel's epilogue / cache-policy template arguments, the TN kernel with / without bias row).
+    Each record carries the launch's algorithmic FLOPs (2 M N K) and algorithmic BYTES (every operand and every output once:
+    DESIGN.md section 4), so that a kernel can be priced against both roofs."""
 
     def __init__(self):
         self.rec = []
@@ -81,56 +106,62 @@ class GemmTimer:
 
     def install(self):
         from open_clip_amd import ops
-        nt, tn = ops.gemm_nt, ops.gemm_tn_accum
+        nt, tn, tn2 = ops.gemm_nt, ops.gemm_tn_accum, ops.gemm_tn_accum2
         timer = self
+
+        def timed(kind, name, flops, nbytes, fn, *args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args, **kw)
+            e1.record()
+            timer.rec.append((kind, name, flops, e0, e1, nbytes))
+            return r
 
         def gemm_nt(epi, a, b, out, **kw):
             if not timer.on:
                 return nt(epi, a, b, out, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = nt(epi, a, b, out, **kw)
-            e1.record()
-            name = "gemm_nt5_kernel<0,false,2> (bf16 out with N >= 1024, non-temporal stores: the QKV projections of ViT-B-32)" if (epi == 0 and b.shape[0] >= 1024) else NT_KERNEL.get(epi, f"gemm_nt epi {epi}")
-            timer.rec.append(("nt", name, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
-            return r
+            M, K, N = a.shape[0], a.shape[1], b.shape[0]
+            name = "gemm_nt5_kernel<0,false,2> (bf16 out with N >= 1024, non-temporal stores: the QKV projections of ViT-B-32)" if (epi == 0 and N >= 1024) else NT_KERNEL.get(epi, f"gemm_nt epi {epi}")
+            nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (4.0 if epi in (2, 4) else 2.0)  # A, B once; the output
+            nbytes += (4.0 * M * N if epi == 2 else 0.0) + (1.0 * M * N if epi in (1, 3) else 0.0)  # fp32 residual read; 8-bit gelu' written / read
+            return timed("nt", name, 2.0 * M * N * K, nbytes, nt, epi, a, b, out, **kw)
 
-        def gemm_tn(a, b, dw, dbias=None, alpha=1.0):
+        def gemm_tn(a, b, dw, dbias=None, *rest, **kw):
             if not timer.on:
-                return tn(a, b, dw, dbias, alpha)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = tn(a, b, dw, dbias, alpha)
-            e1.record()
+                return tn(a, b, dw, dbias, *rest, **kw)
+            M, N, K = a.shape[0], a.shape[1], b.shape[1]
             name = "gemm_tn5_kernel<true> (wgrad + bias gradient)" if dbias is not None else "gemm_tn5_kernel<false> (wgrad)"
-            timer.rec.append(("tn", name, 2.0 * a.shape[0] * a.shape[1] * b.shape[1], e0, e1))
-            return r
+            return timed("tn", name, 2.0 * M * N * K, 2.0 * M * (N + K) + 4.0 * N * K, tn, a, b, dw, dbias, *rest, **kw)
 
-        tn2 = ops.gemm_tn_accum2
-
-        def gemm_tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, alpha=1.0):
+        def gemm_tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, *rest, **kw):
             if not timer.on:
-                return tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, alpha)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, alpha)
-            e1.record()
+                return tn2(a1, b1, dw1, db1, a2, b2, dw2, db2, *rest, **kw)
+            M, K, N = a1.shape[0], b1.shape[1], a1.shape[1] + a2.shape[1]
             name = "gemm_tn5_kernel<true> (wgrad + bias gradient)" if db1 is not None else "gemm_tn5_kernel<false> (wgrad)"
-            timer.rec.append(("tn", name, 2.0 * a1.shape[0] * (a1.shape[1] + a2.shape[1]) * b1.shape[1], e0, e1))
-            return r
+            return timed("tn", name, 2.0 * M * N * K, 2.0 * M * (N + 2 * K) + 4.0 * N * K, tn2, a1, b1, dw1, db1, a2, b2, dw2, db2, *rest, **kw)
 
         ops.gemm_nt, ops.gemm_tn_accum, ops.gemm_tn_accum2 = gemm_nt, gemm_tn, gemm_tn2
 
     @staticmethod
     def _agg(rows):
-        fl, ms, n = sum(r[2] for r in rows), sum(r[3].elapsed_time(r[4]) for r in rows), len(rows)
-        return {"launches": n, "tflop": fl / 1e12, "ms": ms, "tflops": (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0}
+        fl, ms, n, by = sum(r[2] for r in rows), sum(r[3].elapsed_time(r[4]) for r in rows), len(rows), sum(r[5] for r in rows)
+        return {"launches": n, "tflop": fl / 1e12, "ms": ms, "tflops": (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0,
+                "gbytes": by / 1e9, "gbps": (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0}
 
     def summary(self):
         out = {kind: self._agg([r for r in self.rec if r[0] == kind]) for kind in ("nt", "tn")}
         out["all"] = self._agg(self.rec)
         out["by_kernel"] = {name: self._agg([r for r in self.rec if r[1] == name]) for name in sorted({r[1] for r in self.rec})}
         return out
+
+
+def roof(a):
+    """price an aggregate against BOTH roofs: the nearer one is the kernel's bound.  HBM fraction = algorithmic bytes / time over the
+    6.3 TB/s a copy kernel achieves on this chip (the fraction of the 8 TB/s spec rides beside it)"""
+    fm = a["tflops"] / PEAK_BF16_TFLOPS
+    fh = a["gbps"] / HBM_ACHIEVABLE_GBPS
+    return {"bound": "mfma" if fm >= fh else "hbm", "frac": round(max(fm, fh), 4), "frac_mfma": round(fm, 4), "frac_hbm": round(fh, 4),
+            "frac_hbm_of_spec": round(a["gbps"] / HBM_SPEC_GBPS, 4), "algorithmic_gb_per_s": round(a["gbps"], 1)}
 
 
 def _reference_cpu_record():
@@ -256,6 +287,7 @@ def main():
         model.tower_streams = False
     overlap_towers = model.tower_streams
     model.pair_wgrad = not args.no_wgrad_pair
+    model.deterministic = args.deterministic
     if args.grad_checkpointing:
         model.set_grad_checkpointing(True)
     B = args.local_batch
@@ -440,35 +472,48 @@ def main():
             dom_name, dom = max(s["by_kernel"].items(), key=lambda kv: kv[1]["ms"])
             step_ms_ev = elapsed * 1e3 * timed_steps / args.steps  # (approximate: event-timed steps are a little longer than the others)
             traffic, traffic_src, traffic_by = None, None, {}
+            head_sha, csrc_sha = code_identity()
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_stats.py from the PMC passes
             if os.path.exists(tpath) and args.model == "ViT-B-32" and B == 4096:
                 rec = json.load(open(tpath))
-                traffic_src = rec["source"]
+                stale = rec.get("csrc_sha16") != csrc_sha
+                traffic_src = {"how": rec["source"], "git_sha": rec.get("git_sha"), "csrc_sha16": rec.get("csrc_sha16"), "launches_profiled": rec.get("launches"),
+                               "stale": stale, "note": ("PMC passes taken on OTHER kernel sources than the ones this line ran (csrc hash differs)" if stale else
+                                                        "PMC passes taken on exactly the kernel sources this line ran")}
                 traffic_by = rec.get("by_kernel", {})
                 key = dom_name.split(" ")[0]
                 traffic = round(traffic_by[key]["bytes_per_launch"]) if key in traffic_by else round(rec["bytes_per_launch"])
 
             def krec(name, a):
-                r = {"kernel": name, "achieved": round(a["tflops"], 1), "frac": round(a["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": a["launches"],
+                r = {"kernel": name, "achieved": round(a["tflops"], 1), **roof(a), "launches": a["launches"],
                      "avg_launch_ms": round(a["ms"] / max(a["launches"], 1), 4), "algorithmic_tflop_per_launch_avg": round(a["tflop"] / max(a["launches"], 1), 4),
+                     "algorithmic_gb_per_launch_avg": round(a["gbytes"] / max(a["launches"], 1), 4),
                      "share_of_gemm_time": round(a["ms"] / max(allg["ms"], 1e-9), 3)}
                 t = traffic_by.get(name.split(" ")[0])
                 if t:
                     r["traffic"] = round(t["bytes_per_launch"])
                 return r
 
-            line["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(dom["tflops"], 1),
-                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
+            dom_roof = roof(dom)
+            is_mfma = dom_roof["bound"] == "mfma"
+            line["roofline"] = {"bound": dom_roof["bound"], "kernel": dom_name,
+                                "achieved": round(dom["tflops"], 1) if is_mfma else round(dom["gbps"], 1),
+                                "peak": PEAK_BF16_TFLOPS if is_mfma else HBM_ACHIEVABLE_GBPS, "unit": "TFLOP/s" if is_mfma else "GB/s",
+                                "frac": dom_roof["frac"], "frac_mfma": dom_roof["frac_mfma"], "frac_hbm": dom_roof["frac_hbm"],
+                                "peaks": {"mfma_dense_bf16_tflops": PEAK_BF16_TFLOPS, "hbm_achievable_gbps": HBM_ACHIEVABLE_GBPS, "hbm_spec_gbps": HBM_SPEC_GBPS,
+                                          "rule": "a kernel's bound is the roof it is nearer to: max(algorithmic FLOPs / time / MFMA peak, algorithmic bytes / time / "
+                                                  "6.3 TB/s); both fractions ride on every entry"},
                                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "launches": dom["launches"],
                                 "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                                 "algorithmic_tflop_per_launch_avg": round(dom["tflop"] / max(dom["launches"], 1), 4),
+                                "algorithmic_gb_per_launch_avg": round(dom["gbytes"] / max(dom["launches"], 1), 4),
                                 "dominant_by": "largest total time among the GEMM kernel instantiations inside the event-timed steps",
                                 "by_kernel": [krec(n, a) for n, a in sorted(s["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])],
-                                "gemm_nt_family": {"achieved": round(nt["tflops"], 1), "frac": round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": nt["launches"],
+                                "gemm_nt_family": {"achieved": round(nt["tflops"], 1), **roof(nt), "launches": nt["launches"],
                                                    "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
-                                "gemm_tn_family": {"achieved": round(tn["tflops"], 1), "frac": round(tn["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": tn["launches"],
+                                "gemm_tn_family": {"achieved": round(tn["tflops"], 1), **roof(tn), "launches": tn["launches"],
                                                    "avg_launch_ms": round(tn["ms"] / max(tn["launches"], 1), 4)},
-                                "all_gemm_launches": {"achieved": round(allg["tflops"], 1), "frac": round(allg["tflops"] / PEAK_BF16_TFLOPS, 4), "launches": allg["launches"]},
+                                "all_gemm_launches": {"achieved": round(allg["tflops"], 1), **roof(allg), "launches": allg["launches"]},
                                 "event_timed_steps": timed_steps,
                                 "event_timed_steps_mode": ("one tower at a time (same two streams, the image tower's held back behind the text tower's), no wgrad "
                                                            f"side stream: every GEMM launch alone on the chip; the other {args.steps - timed_steps} timed steps "
@@ -476,14 +521,35 @@ def main():
                                                            "as every step (wgrad launches run on a side stream under the LayerNorm / attention backward kernels of "
                                                            "their block unless --no-wgrad-pair: their events then time a co-scheduled kernel)"),
                                 "gemm_share_of_step": round(allg["ms"] / step_ms_ev, 3)}
+            line["code"] = {"git_sha": head_sha, "csrc_sha16": csrc_sha}
         if world == 1 and not args.no_eager_baseline and not args.siglip:
             micro.clear()
+            del batch
             torch.cuda.empty_cache()
-            try:
-                line["torch_eager_baseline"] = torch_eager_baseline(args.model, min(args.eager_batch, B), dev)
-                line["torch_eager_baseline"]["native_over_eager"] = round(value / line["torch_eager_baseline"]["value"], 2)
-            except Exception as e:  # the baseline must never take the bench line down with it
-                line["torch_eager_baseline"] = {"error": repr(e)[:300]}
+            eb = min(args.eager_batch, B)
+            while True:  # the bench's own batch when it fits (like for like); halve on out-of-memory
+                try:
+                    rec = torch_eager_baseline(args.model, eb, dev)
+                    break
+                except torch.OutOfMemoryError:
+                    torch.cuda.empty_cache()
+                    if eb <= 256:
+                        rec = {"error": "out of memory at batch 256"}
+                        break
+                    eb //= 2
+                except Exception as e:  # the baseline must never take the bench line down with it
+                    rec = {"error": repr(e)[:300]}
+                    break
+            if "value" in rec:
+                # like for like: native and eager both at the bench's batch; `native_dense_over_eager` also runs the SAME work (all
+                # context_length positions of every caption), `native_over_eager` includes what the packed text tower saves
+                rec["native_over_eager"] = round(value / rec["value"], 2)
+                rec["native_over_eager_is"] = "shipped native step (packed text tower, pooled last block) / eager step, both at the batch above" if model_ref.pack_text else "native / eager"
+                if dense_text is not None:
+                    rec["native_dense_over_eager"] = round(dense_text["value"] / rec["value"], 2)
+                    rec["native_dense_over_eager_is"] = "native step with --dense-text (every position of every caption, as eager runs it) / eager step"
+                rec["same_batch_as_native"] = bool(eb == B)
+            line["torch_eager_baseline"] = rec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(line), flush=True)

@@ -34,12 +34,12 @@ OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
     } else if (EPI == OCN_EPI_BIAS_GELU) {
         float g1, d1;
         gelu_both(v + b, g1, d1);
-        a.aux[o] = f2bf(d1);
+        a.aux[o] = (unsigned char)(dgelu_q_bits(d1) & 255u);
         ((bf16*)a.out)[o] = f2bf(g1);
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
         ((float*)a.out)[o] = v + b + a.resid[o];
     } else if (EPI == OCN_EPI_DGELU) {
-        ((bf16*)a.out)[o] = f2bf((v + b) * bf2f(a.aux[o]));
+        ((bf16*)a.out)[o] = f2bf((v + b) * dgelu_unq(a.aux[o]));
     } else {
         ((float*)a.out)[o] = v * a.alpha + b;
     }
@@ -88,8 +88,7 @@ OCN_DEV void epi_prefetch(const GemmNtArgs& a, int gm_base, int gn, int lane, Ep
         if (EPI == OCN_EPI_BIAS_RESID_F32) {
             b.r[it] = *(const f32x4*)(a.resid + o);
         } else {
-            const bf16x4 p4 = *(const bf16x4*)(a.aux + o);
-            b.r[it] = (f32x4){bf2f(p4[0]), bf2f(p4[1]), bf2f(p4[2]), bf2f(p4[3])};
+            b.r[it] = dgelu_unpack4(*(const unsigned*)(a.aux + o));
         }
     }
 }
@@ -110,8 +109,7 @@ OCN_DEV void epi_apply_store(const GemmNtArgs& a, int gm, int gn, f32x4 v, f32x4
             gv[e] = g1;
             dv[e] = d1;
         }
-        bf16x4 p4 = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])};  // aux = gelu'(pre-activation)
-        *(bf16x4*)(a.aux + o) = p4;
+        *(unsigned*)(a.aux + o) = dgelu_pack4(dv[0], dv[1], dv[2], dv[3]);  // aux = gelu'(pre-activation) in 8 bits
         bf16x4 o4 = {f2bf(gv[0]), f2bf(gv[1]), f2bf(gv[2]), f2bf(gv[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
@@ -449,7 +447,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     OCN_CHECK_ARG(epilogue != OCN_EPI_BIAS_RESID_F32 || resid, "ocn_gemm_nt: residual epilogue needs resid");
     OCN_CHECK_ARG((epilogue != OCN_EPI_BIAS_GELU && epilogue != OCN_EPI_DGELU) || aux, "ocn_gemm_nt: gelu epilogues need aux");
     GemmNtArgs a;
-    a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (bf16*)aux;
+    a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (unsigned char*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
     a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0;
     hipStream_t st = (hipStream_t)stream;

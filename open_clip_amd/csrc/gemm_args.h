@@ -8,7 +8,7 @@ struct GemmNtArgs {
     void* out;
     const float* bias;
     const float* resid;
-    bf16* aux;
+    unsigned char* aux;  // saved gelu' in 8 bits (ocn_common.h: dgelu_pack4 / dgelu_unpack4), [M, ldc] bytes
     int lda, ldb, ldc, M, N, K;
     float alpha;
     int tiles_n, ntiles;

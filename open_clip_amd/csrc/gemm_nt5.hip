@@ -30,6 +30,7 @@ namespace {
 
 __device__ long long g_nt5_trace[1024];  // developer timeline (DBG kernels only): 2 workgroups x 8 tiles x 8 stamps
 
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 constexpr int UNIT = 16384;
 constexpr int RING_BYTES = 8 * UNIT;
 constexpr int STG_BYTES = 4096;
@@ -46,6 +47,13 @@ constexpr int LDS_BYTES = RING_BYTES + 8 * STG_BYTES;  // 163840 = all of a CU's
 // Epilogue staging goes through inline-asm LDS ops: for compiler-visible LDS reads hipcc inserts s_waitcnt vmcnt(0)
 // (it cannot prove they do not alias an in-flight LDS-DMA), which would serialize every global store of the epilogue
 // behind a full memory round trip (measured: 10 us per tile instead of ~1).
+OCN_DEV void lds_w32(unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+OCN_DEV void lds_r64x4(unsigned a0, u32x2_t& d0, u32x2_t& d1, u32x2_t& d2, u32x2_t& d3) {  // rows it*8 + (lane>>3) of the padded u8 staging image
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:576\n\tds_read_b64 %2, %4 offset:1152\n\tds_read_b64 %3, %4 offset:1728\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                 : "v"(a0)
+                 : "memory");
+}
 OCN_DEV void lds_w64(unsigned addr, bf16x4 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 OCN_DEV void lds_w128(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 template <typename T>
@@ -96,7 +104,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const unsigned omask = win ? 0xfff0u : ~0u;
     const long m_win = win ? (long)((blockIdx.x * 65536L) / ((long)a.ldc * (OUT_F32 ? 4 : 2))) : m0;
     const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m_win, m_st, a.ldc, OUT_F32 ? 4 : 2);
-    const __amdgpu_buffer_rsrc_t r_aux = aux_is_out ? tile_rsrc(a.aux, m_win, m_st, a.ldc, 2) : tile_rsrc(a.aux, m0, m_ld, a.ldc, 2);
+    const __amdgpu_buffer_rsrc_t r_aux = aux_is_out ? tile_rsrc(a.aux, m_win, m_st, a.ldc, 1) : tile_rsrc(a.aux, m0, m_ld, a.ldc, 1);  // gelu' in 8 bits
     const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 4);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
     // Bias is fetched ONCE, before any store of this tile is issued (a later load would have to wait behind the stores):
@@ -183,16 +191,19 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     if (dbg) dbg[5] = wall_clock64();
     const int row_w = wm * 128;  // this wave's first row inside the tile
     if (BF16_STAGED) {
-        constexpr int ROUNDS = (EPI == OCN_EPI_BIAS_GELU) ? 2 : 1;
         const int gn = gn_w + rd_chunk * 8;
         const unsigned col_off = gn < a.N ? (unsigned)gn * 2u : OOB;
+        const unsigned col_off_aux = gn < a.N ? (unsigned)gn : OOB;  // the saved derivative: one byte per element
+        // u8 staging image of a 32 x 64 sub-block: rows of 64 bytes padded to 72 (a lane writes the 4 bytes of its register quad, reads 8)
+        const unsigned aw_addr = stg + lr * 72 + lh * 4, ar_addr = stg + rd_row * 72 + rd_chunk * 8;
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // GELU: gelu(v) AND gelu'(v) come out of one evaluation of the shared erf / exp parts; the derivative is what
-                // is saved for the backward (aux), whose epilogue is then a plain multiply (EPI_DGELU below)
-                bf16x4 pk[ROUNDS][2][4];
+                // is saved for the backward (aux, 8-bit fixed point), whose epilogue is then a plain multiply (EPI_DGELU below)
+                bf16x4 pk[2][4];
+                unsigned dq[2][4];
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -210,27 +221,39 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                                     dv[e] = d1;
                                 }
                             }
-                            pk[0][hb][g] = (bf16x4){f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])};
-                            pk[ROUNDS - 1][hb][g] = (bf16x4){f2bf(gv[0]), f2bf(gv[1]), f2bf(gv[2]), f2bf(gv[3])};
-                        } else {
-                            pk[0][hb][g] = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                            dq[hb][g] = dgelu_pack4(dv[0], dv[1], dv[2], dv[3]);
+                            v = gv;
                         }
+                        pk[hb][g] = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     }
-#pragma unroll
-                for (int rnd = 0; rnd < ROUNDS; ++rnd) {
-                    if (dbg && ha == 1 && s == 0 && rnd == 0) dbg[6] = wall_clock64();
+                if constexpr (EPI == OCN_EPI_BIAS_GELU) {
+                    if (dbg && ha == 1 && s == 0) dbg[6] = wall_clock64();
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk[rnd][hb][g]);
-                    const bool to_aux = (EPI == OCN_EPI_BIAS_GELU && rnd == 0);
+                        for (int g = 0; g < 4; ++g) lds_w32(aw_addr + (hb * 8 + g * 2) * 4, dq[hb][g]);
+                    u32x2_t d8[4];
+                    lds_r64x4(ar_addr, d8[0], d8[1], d8[2], d8[3]);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
+                        const unsigned off = (unsigned)(row * a.ldc) + col_off_aux;
+                        __builtin_amdgcn_raw_buffer_store_b64(d8[it], r_aux, off & omask, 0, AUX & 2);
+                    }
+                }
+                {
+                    if (dbg && ha == 1 && s == 0 && EPI != OCN_EPI_BIAS_GELU) dbg[6] = wall_clock64();
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk[hb][g]);
                     bf16x8 d[4];
                     lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
                         const unsigned off = (unsigned)(row * a.ldc) * 2u + col_off;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), to_aux ? r_aux : r_out, off & omask, 0, AUX & 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d[it]), r_out, off & omask, 0, AUX & 2);
                     }
                 }
             }
@@ -250,11 +273,11 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         // Epilogue operands (residual rows / saved gelu') sit in a ring of DEPTH blocks: block k + DEPTH - 1 is requested before the
         // stores of block k are issued.  vmcnt retires loads AND stores in issue order, so waiting for block k's operand also waits
         // for every store issued before its request: with DEPTH = 2 that is the stores of block k - 2, whose HBM acknowledgement is
-        // what the epilogue then idles on.  AUX bit 5 (32) deepens the ring: the dGELU epilogue (8 bytes per lane and row) requests
-        // ALL eight blocks before its first store (64 VGPRs, no wait ever sits behind a store), the fp32 residual (16 bytes) runs
-        // four blocks ahead (64 VGPRs).
+        // what the epilogue then idles on.  AUX bit 5 (32) deepens the ring: the dGELU epilogue (4 bytes per lane and row: the saved
+        // derivatives are 8-bit) requests ALL eight blocks before its first store (32 VGPRs, no wait ever sits behind a store), the
+        // fp32 residual (16 bytes) runs four blocks ahead (64 VGPRs).
         constexpr int DEPTH = !HAS_EX ? 1 : ((AUX & 32) ? (EPI == OCN_EPI_DGELU ? 8 : 4) : 2);
-        typedef typename std::conditional<EPI == OCN_EPI_DGELU, bf16x4, f32x4>::type ex_t;
+        typedef typename std::conditional<EPI == OCN_EPI_DGELU, unsigned, f32x4>::type ex_t;  // dGELU: 4 saved derivatives in 8 bits each
         ex_t ex[DEPTH][4];
         auto load_ex = [&](int blk, ex_t (&e)[4]) {
 #pragma unroll
@@ -262,7 +285,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                 if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
                     e[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
                 } else if constexpr (EPI == OCN_EPI_DGELU) {
-                    e[it] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r_aux, byte_off(blk, it, 2u), 0, (AUX & 8) ? 2 : 0));
+                    e[it] = __builtin_amdgcn_raw_buffer_load_b32(r_aux, byte_off(blk, it, 1u), 0, (AUX & 8) ? 2 : 0);
                 }
             }
         };
@@ -290,8 +313,8 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                 if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[blk % DEPTH][it]), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
                 } else if constexpr (EPI == OCN_EPI_DGELU) {
-                    const bf16x4 p4 = ex[blk % DEPTH][it];  // gelu'(pre-activation), saved by the forward epilogue
-                    const bf16x4 o4 = {f2bf(v[0] * bf2f(p4[0])), f2bf(v[1] * bf2f(p4[1])), f2bf(v[2] * bf2f(p4[2])), f2bf(v[3] * bf2f(p4[3]))};
+                    const f32x4 p4 = dgelu_unpack4(ex[blk % DEPTH][it]);  // gelu'(pre-activation), saved by the forward epilogue
+                    const bf16x4 o4 = {f2bf(v[0] * p4[0]), f2bf(v[1] * p4[1]), f2bf(v[2] * p4[2]), f2bf(v[3] * p4[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u) & omask, 0, AUX & 2);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);

@@ -200,7 +200,7 @@ def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
     xmid = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, cache.get(wo, "n"), ops.empty((M, C), F32, x), bias=bo, resid=x)
     h2, _, mean2, rstd2 = ops.layernorm_fwd(xmid, ln2w, ln2b)
     Fd = wfc.shape[0]
-    f = ops.empty((M, Fd), BF16, x)
+    f = ops.empty((M, Fd), torch.uint8, x)  # gelu'(pre-activation) in 8-bit fixed point: all the backward needs of it
     g = ops.gemm_nt(ops.EPI_BIAS_GELU, h2, cache.get(wfc, "n"), ops.empty((M, Fd), BF16, x), bias=bfc, aux=f)
     y = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g, cache.get(wproj, "n"), ops.empty((M, C), F32, x), bias=bproj, resid=xmid)
     return y, (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g)
@@ -293,7 +293,7 @@ def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None):
     xmid_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a_p, cache.get(wo, "n"), ops.empty((B, C), F32, x), bias=bo, resid=x_p)
     h2_p, _, mean2, rstd2 = ops.layernorm_fwd(xmid_p, ln2w, ln2b)
     Fd = wfc.shape[0]
-    f_p = ops.empty((B, Fd), BF16, x)
+    f_p = ops.empty((B, Fd), torch.uint8, x)
     g_p = ops.gemm_nt(ops.EPI_BIAS_GELU, h2_p, cache.get(wfc, "n"), ops.empty((B, Fd), BF16, x), bias=bfc, aux=f_p)
     y_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g_p, cache.get(wproj, "n"), ops.empty((B, C), F32, x), bias=bproj, resid=xmid_p)
     return y_p, (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p)

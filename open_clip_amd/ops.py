@@ -43,7 +43,8 @@ def empty(shape, dtype, like):
 
 # ---- GEMMs ------------------------------------------------------------------------------------------
 def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
-    """out[M,N] = a[M,K] @ b[N,K]^T (+ epilogue); a, b bf16; out bf16 or fp32 depending on ``epi``."""
+    """out[M,N] = a[M,K] @ b[N,K]^T (+ epilogue); a, b bf16; out bf16 or fp32 depending on ``epi``.  ``aux`` (uint8 [M,N]) holds the
+    GELU derivative in 8-bit fixed point (written by EPI_BIAS_GELU, read by EPI_DGELU; see ``dgelu_encode`` / ``dgelu_decode``)."""
     pa, lda = _chk2d(a, BF16, "a")
     pb, ldb = _chk2d(b, BF16, "b")
     odt = F32 if epi in (EPI_BIAS_RESID_F32, EPI_F32) else BF16
@@ -57,9 +58,22 @@ def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
     if aux is not None and (aux.shape != out.shape or aux.stride(0) != ldc):
         raise RuntimeError("gemm_nt: aux must match out")
     _lib.call("ocn_gemm_nt", epi, pa, lda, pb, ldb, po, ldc, M, N, K, _chk(bias, F32, "bias"),
-              0 if resid is None else _chk2d(resid, F32, "resid")[0], 0 if aux is None else _chk2d(aux, BF16, "aux")[0],
+              0 if resid is None else _chk2d(resid, F32, "resid")[0], 0 if aux is None else _chk2d(aux, torch.uint8, "aux")[0],
               float(alpha), _stream())
     return out
+
+
+DGELU_SCALE, DGELU_OFFSET = 200.0, 0.13  # csrc/ocn_common.h: q = round((gelu' + 0.13) * 200), |error| <= 0.0025
+
+
+def dgelu_decode(q):
+    """the values the backward epilogue multiplies with, from the stored bytes (test / tooling helper; torch arithmetic)"""
+    return q.float() / DGELU_SCALE - DGELU_OFFSET
+
+
+def dgelu_encode(d):
+    """bytes for given derivative values in [-0.13, 1.145] (test / tooling helper)"""
+    return torch.round((d.float() + DGELU_OFFSET) * DGELU_SCALE).clamp_(0, 255).to(torch.uint8)
 
 
 def gemm_tn_accum(a, b, dw, dbias=None, alpha=1.0, deterministic=False):

@@ -52,9 +52,9 @@ def test_gemm_nt_at_bench_shape(dev, name, M, N, K, epi, with_bias):
     resid = torch.randn(M, N, device=dev, generator=g) if epi == ops.EPI_BIAS_RESID_F32 else None
     aux = None
     if epi == ops.EPI_BIAS_GELU:
-        aux = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        aux = torch.full((M, N), 255, device=dev, dtype=torch.uint8)  # 255 is outside the code range [0, 252]: a row never written shows
     elif epi == ops.EPI_DGELU:
-        aux = bf(torch.rand(M, N, device=dev, generator=g) * 1.25 - 0.125)  # the range of gelu'
+        aux = torch.randint(0, 253, (M, N), device=dev, generator=g, dtype=torch.uint8)  # the 8-bit codes of gelu' (ops.dgelu_decode)
     ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux)
     torch.cuda.synchronize()
     worst, worst_aux, bad = 0.0, 0.0, 0
@@ -69,7 +69,7 @@ def test_gemm_nt_at_bench_shape(dev, name, M, N, K, epi, with_bias):
         elif epi == ops.EPI_BIAS_RESID_F32:
             ref = acc + resid[sl]
         elif epi == ops.EPI_DGELU:
-            ref = acc * aux[sl].float()
+            ref = acc * ops.dgelu_decode(aux[sl])
         else:
             ref = acc
         got = out[sl].float()
@@ -78,13 +78,13 @@ def test_gemm_nt_at_bench_shape(dev, name, M, N, K, epi, with_bias):
         if not f32out:
             bad += int(((got - ref).abs() > ref.abs() * 2.0 ** -7 + 2e-3).sum())
         if ref2 is not None:
-            got2 = aux[sl].float()
-            assert torch.isfinite(got2).all(), f"{name}: saved gelu' rows {r0}.. non-finite"
+            assert int(aux[sl].max()) <= 252, f"{name}: saved gelu' rows {r0}.. hold a byte outside the code range (tile never written?)"
+            got2 = ops.dgelu_decode(aux[sl])
             worst_aux = max(worst_aux, rel_l2(got2, ref2))
-            bad += int(((got2 - ref2).abs() > ref2.abs() * 2.0 ** -7 + 2e-3).sum())
+            bad += int(((got2 - ref2).abs() > 2.6e-3).sum())  # half a step of the 8-bit fixed point (1/400) + the erf approximation
     _report(f"bench-shape gemm_nt {name:12s} [{M}x{N}x{K}] {EPI_NAMES[epi]:15s} rel_l2={worst:.3e}" + (f" aux rel_l2={worst_aux:.3e}" if epi == 1 else ""))
     assert worst <= (2e-5 if f32out else 2.5e-3), (name, worst)
-    assert worst_aux <= 2.5e-3 and bad == 0, (name, worst_aux, bad)
+    assert worst_aux <= 4e-3 and bad == 0, (name, worst_aux, bad)  # 8-bit gelu': rms error 0.0014 on values of rms ~0.6
 
 
 TN_CASES = []

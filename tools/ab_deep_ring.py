@@ -39,7 +39,7 @@ for name, epi, M, N, K in SHAPES:
     bias = torch.randn(N, device=dev, generator=g)
     f32out = epi == ops.EPI_BIAS_RESID_F32
     resid = torch.randn(M, N, device=dev, generator=g) if f32out else None
-    aux = torch.rand(M, N, device=dev, generator=g).bfloat16() if epi == ops.EPI_DGELU else None
+    aux = torch.randint(0, 253, (M, N), device=dev, generator=g, dtype=torch.uint8) if epi == ops.EPI_DGELU else None
     outs = []
     for v in (0, FLIP):
         _lib.call("ocn_set_gemm_variant", v)

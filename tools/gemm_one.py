@@ -17,7 +17,7 @@ if kind == "nt":
     f32out = epi in (2, 4)
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
     resid = torch.randn(M, N, device=dev) if epi == 2 else None
-    aux = torch.randn(M, N, device=dev).bfloat16() if epi in (1, 3) else None
+    aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (1, 3) else None
     bias = torch.randn(N, device=dev)
     for _ in range(iters):
         ops.gemm_nt(epi, a, b, out, bias=bias, resid=resid, aux=aux)

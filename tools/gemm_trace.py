@@ -17,7 +17,7 @@ b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
 f32out = epi in (2, 4)
 out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
 resid = torch.randn(M, N, device=dev) if epi == 2 else None
-aux = torch.randn(M, N, device=dev).bfloat16() if epi in (1, 3) else None
+aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (1, 3) else None
 bias = torch.randn(N, device=dev)
 for variant in (5, 5, 5 + 256 * 64):
     _lib.call("ocn_set_gemm_variant", variant)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# gpurun wrapper: stamps the tree's identity into .head_sha (shipped with the snapshot, not tracked) so that what runs on the GPU box can
+# name the commit it ran.  usage: tools/gpu.sh TIMEOUT 'command'
+cd "$(dirname "$0")/.."
+sha=$(git rev-parse --short=12 HEAD)
+git diff --quiet HEAD -- . ':!gpurun_out' || sha="${sha}-dirty"
+echo "$sha" > .head_sha
+exec /usr/local/graft/bin/gpurun --timeout "$1" -- "$2"

@@ -36,7 +36,7 @@ for name, M, N, K, epi in [("img fc", Mi, 3072, 768, 0), ("img fc gelu", Mi, 307
     a = torch.randn(M, K, device=dev).bfloat16()
     b = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == 1 else None
+    aux = torch.empty(M, N, device=dev, dtype=torch.uint8) if epi == 1 else None
     bias = torch.randn(N, device=dev)
     fn = lambda: ops.gemm_nt(epi, a, b, out, bias=bias, aux=aux)
     fn()

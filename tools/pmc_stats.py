@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; csv output).
-usage: python tools/pmc_stats.py fetch.csv write.csv
+usage: python tools/pmc_stats.py fetch.csv write.csv [out.json [git_sha]]
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts
 128-byte read requests at 64 B, i.e. reports half of the bytes of wide coalesced reads -> doubled here.  WRITE_SIZE is
 used as reported (uncalibrated per the guide; the elementwise kernels below serve as the calibration points)."""
@@ -49,6 +49,13 @@ def main():
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1`; "
                          "FETCH_SIZE doubled (gfx950 counts 128-byte requests at 64 B), KiB units"}
         rec["bytes_per_launch"] = rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"]
+        # which code these passes saw: bench.py compares csrc_sha16 with the kernel sources it runs and marks a stale quote on its line
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import code_identity
+        rec["git_sha"], rec["csrc_sha16"] = code_identity()
+        if len(sys.argv) > 4:
+            rec["git_sha"] = sys.argv[4]
         # per kernel instantiation, keyed as bench.py names them ("gemm_nt5_kernel<2,false,40>", "gemm_tn5_kernel<true>")
         rec["by_kernel"] = {}
         for tot, n, rd, wr, us, k in rows:

@@ -40,7 +40,7 @@ def nt_sweep():
             f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
             out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
-            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
             for band in bands + [0]:
                 _lib.call("ocn_set_gemm_variant", 5 | (band << 16))
@@ -146,7 +146,7 @@ def ntstore_sweep():
             f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
             out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
-            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
             for mask in (0, 16, 0, 16, 0, 16):
                 _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
@@ -190,7 +190,7 @@ def percu_sweep():
         f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
         resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
-        aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+        aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
         row = []
         for k in (1, 2, 3, 4, 1, 2):
             _lib.call("ocn_set_tuning", 10, k)
@@ -215,7 +215,7 @@ def stagger_sweep():
             f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
             out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
-            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
             for st in (63, 2, 4, 6, 8, 12, 0):
                 _lib.call("ocn_set_gemm_variant", 5 | (st << 21))
@@ -241,7 +241,7 @@ def epi_ablation_sweep():
             f32out = epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32)
             out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
             resid = torch.randn(M, N, device=dev) if epi == ops.EPI_BIAS_RESID_F32 else None
-            aux = torch.randn(M, N, device=dev).bfloat16() if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
+            aux = torch.randint(0, 253, (M, N), device=dev, dtype=torch.uint8) if epi in (ops.EPI_BIAS_GELU, ops.EPI_DGELU) else None
             row = []
             for mask, tag in ((0, "full"), (0x80000, "stores->L2 window"), (32, "-stores"), (32 | 128, "-stores-loads"), (32 | 128 | 1, "-stores-loads-valu"), (0, "full")):
                 _lib.call("ocn_set_gemm_variant", 5 | (mask << 8))
