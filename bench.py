@@ -65,6 +65,11 @@ def parse():
                     "inside the timed region")
     ap.add_argument("--force-ddp", action="store_true", help="developer: with one process, still wrap the model in DistributedDataParallel over a "
                     "one-rank RCCL group (what the gradient buckets, their copies and the reducer hooks cost without any communication)")
+    ap.add_argument("--native-allreduce", action="store_true", help="gradient all-reduce WITHOUT DistributedDataParallel: per-block in-place all-reduce of the "
+                    "backward's own gradient arenas from post-accumulate hooks (open_clip_amd/grad_sync.py; RCCL through the C ABI, or the process "
+                    "group with --dist-backend gloo); with one process: a one-rank communicator (what the hooks and launches cost)")
+    ap.add_argument("--native-comm", action="store_true", help="N>1: the loss's feature all-gather / reduce-scatter through the C ABI's RCCL communicator "
+                    "(ocn_comm_*) instead of torch.distributed's process group")
     ap.add_argument("--bucket-cap-mb", type=int, default=128)
     ap.add_argument("--data-ranks", type=int, default=1, help="developer: with one process, use the concatenation of the batches R ranks would "
                     "get (what a world_size-R run sees as its global batch; tests/test_bench_gpu.py)")
@@ -321,17 +326,28 @@ def main():
         gh = torch.Generator().manual_seed(99 + rank)
         host_pool = [(torch.randint(0, 256, (B, S, S, 3), generator=gh, dtype=torch.uint8).pin_memory(), micro[j % F_ACC]["text"].cpu().pin_memory())
                      for j in range(2)]
-        pipe = DeviceBatchPipeline(dev, (B, S, S, 3), (B, cfg["text_cfg"]["context_length"]), depth=max(2, F_ACC + 1))
+        # the packed text layout is computed on the host with the batch (HostTextPlan): the step has no host synchronisation left
+        pipe = DeviceBatchPipeline(dev, (B, S, S, 3), (B, cfg["text_cfg"]["context_length"]), depth=max(2, F_ACC + 1),
+                                   plan_text_vocab=(cfg["text_cfg"]["vocab_size"] if model.pack_text else None), attn_buckets=model.attn_buckets)
         pipe.submit(*host_pool[0])
+    native_comm = None
+    if (args.native_allreduce or args.native_comm) and args.dist_backend == "nccl":
+        from open_clip_amd.comm import NativeComm  # RCCL behind the C ABI; the 128-byte id travels through the process group once
+        native_comm = NativeComm.from_process_group(rank, world) if world > 1 else NativeComm(NativeComm.make_unique_id(), 0, 1)
+    loss_comm = native_comm if (args.native_comm and world > 1) else None
     if args.siglip:
         from open_clip_amd.loss import NativeSigLipLoss
-        loss_fn = NativeSigLipLoss(rank=rank, world_size=world)
+        loss_fn = NativeSigLipLoss(rank=rank, world_size=world, comm=loss_comm)
     else:
         loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
-                                 row_sharded=(world > 1 and not args.naive_global_loss))
+                                 row_sharded=(world > 1 and not args.naive_global_loss), comm=loss_comm)
     opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=args.lr, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
-    if world > 1 or args.force_ddp:
+    grad_sync = None
+    if args.native_allreduce:
+        from open_clip_amd.grad_sync import NativeGradSync
+        grad_sync = NativeGradSync(model, world, comm=native_comm)
+    elif world > 1 or args.force_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_cap_mb, gradient_as_bucket_view=True)
 
     timer = GemmTimer()
@@ -361,6 +377,8 @@ def main():
             out = net(image=b["image"], text=b["text"])
             loss = loss_fn(**out)
             loss.backward()
+            if grad_sync is not None:
+                grad_sync.finish()
             if pipe is not None:
                 pipe.release(b)
         else:
@@ -378,9 +396,15 @@ def main():
                 inputs = {k: torch.cat(feats[k][:j] + [o[k]] + feats[k][j + 1:]) for k in feats}
                 extra_in = {"logit_bias": o["logit_bias"]} if "logit_bias" in o else {}
                 loss = loss_fn(**inputs, logit_scale=o["logit_scale"], **extra_in)
-                loss.backward()
+                if grad_sync is not None and j + 1 < len(held):
+                    with grad_sync.no_sync():  # the micro-batches before the last one only accumulate (DDP: no_sync)
+                        loss.backward()
+                else:
+                    loss.backward()
                 if pipe is not None:
                     pipe.release(b)
+            if grad_sync is not None:
+                grad_sync.finish()
         opt.step()
         with torch.no_grad():
             model.logit_scale.clamp_(0, math.log(100))  # image_text_task.py:91-101
@@ -452,7 +476,10 @@ def main():
                                    + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
                                       if world > 1 else "world_size 1 (no all-gather)"),
                        "model": args.model, "global_batch": B * F_ACC * world, "local_batch": B, "accum_freq": F_ACC, "parallelism": f"dp{world}",
-                       "ddp": bool(world > 1 or args.force_ddp), "bucket_cap_mb": args.bucket_cap_mb,
+                       "ddp": bool((world > 1 or args.force_ddp) and grad_sync is None), "bucket_cap_mb": args.bucket_cap_mb,
+                       "gradient_allreduce": ("native per-block in-place all-reduce (open_clip_amd/grad_sync.py)" + (" over RCCL through the C ABI" if native_comm is not None else " over the process group")
+                                              if grad_sync is not None else ("DistributedDataParallel" if (world > 1 or args.force_ddp) else "none (one process)")),
+                       "loss_collectives": "C ABI (ocn_comm_*)" if loss_comm is not None else ("torch.distributed" if world > 1 else "none"),
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "text_tower": text_rows_note,
                        "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
@@ -553,6 +580,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(line), flush=True)
+    if grad_sync is not None and rank == 0 and os.environ.get("OCN_BENCH_VERBOSE"):
+        print("grad_sync stats:", {k: (v if not isinstance(v, list) else v[-30:]) for k, v in grad_sync.stats.items()}, file=sys.stderr)
+    if native_comm is not None:
+        native_comm.close()
     if world > 1 or args.force_ddp:
         torch.distributed.destroy_process_group()
 

@@ -251,6 +251,8 @@ int ocn_comm_destroy(void* comm);
 int ocn_comm_allgather(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, ocn_stream_t stream);
 int ocn_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, ocn_stream_t stream);
 int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream);
+/* in-place MEAN over ranks (ncclAvg): the gradient all-reduce that replaces DistributedDataParallel's reducer (base_task.py:219-232) */
+int ocn_comm_allreduce_avg(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream);
 
 /* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
 int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ocn_comm_allgather": [_p, _p, _p, _l, _i, _p],
     "ocn_comm_reduce_scatter_sum": [_p, _p, _p, _l, _i, _p],
     "ocn_comm_allreduce_sum": [_p, _p, _l, _i, _p],
+    "ocn_comm_allreduce_avg": [_p, _p, _l, _i, _p],
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }

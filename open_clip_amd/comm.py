@@ -68,7 +68,12 @@ class NativeComm:
     def all_reduce_sum(self, t):
         _lib.call("ocn_comm_allreduce_sum", self._comm, _check(t, "tensor"), t.numel(), _dt(t), self._stream())
 
+    def all_reduce_avg(self, t):
+        _lib.call("ocn_comm_allreduce_avg", self._comm, _check(t, "tensor"), t.numel(), _dt(t), self._stream())
+
     def close(self):
+        """destroys the communicator; pending collectives are waited for first (ncclCommDestroy does not order itself behind the streams)"""
         if self._comm:
+            torch.cuda.synchronize()
             _lib.call("ocn_comm_destroy", self._comm)
             self._comm = None

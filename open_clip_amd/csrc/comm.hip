@@ -13,7 +13,7 @@ namespace {
 
 typedef struct { char internal[128]; } UniqueId;  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
 typedef void* Comm;                               // ncclComm_t
-enum { kSum = 0, kFloat32 = 7, kBfloat16 = 9 };   // ncclSum, ncclFloat32, ncclBfloat16 (rccl.h)
+enum { kSum = 0, kAvg = 4, kFloat32 = 7, kBfloat16 = 9 };   // ncclSum, ncclAvg, ncclFloat32, ncclBfloat16 (rccl.h)
 
 struct Rccl {
     void* handle = nullptr;
@@ -111,5 +111,14 @@ extern "C" int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int 
     Rccl* R = rccl();
     OCN_CHECK_ARG(R && comm && buf && count > 0, "ocn_comm_allreduce_sum: bad arguments");
     OCN_RCCL(R->AllReduce(buf, buf, (size_t)count, dtype_of(dtype), kSum, (Comm)comm, (hipStream_t)stream), "ocn_comm_allreduce_sum");
+    return OCN_OK;
+}
+
+// buf [count] = element-wise MEAN over ranks, in place (ncclAvg): the gradient all-reduce of the data-parallel step -- what DDP's reducer
+// computes (base_task.py:219-232), issued per residual block on the block's own gradient arena (open_clip_amd/grad_sync.py)
+extern "C" int ocn_comm_allreduce_avg(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm && buf && count > 0, "ocn_comm_allreduce_avg: bad arguments");
+    OCN_RCCL(R->AllReduce(buf, buf, (size_t)count, dtype_of(dtype), kAvg, (Comm)comm, (hipStream_t)stream), "ocn_comm_allreduce_avg");
     return OCN_OK;
 }

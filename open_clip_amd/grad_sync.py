@@ -1,0 +1,200 @@
+"""Gradient all-reduce of the data-parallel step without ``DistributedDataParallel`` (reference: the DDP wrap of
+``src/open_clip/task/base_task.py:219-232``).
+
+DDP's reducer copies every gradient into its own buckets before it can reduce them (605 MB per step for ViT-B-32: +1.6 ... +6.9 ms on
+ONE GPU before any byte moves over xGMI).  The native backward already leaves the gradients where a collective wants them: each residual
+block writes its twelve parameter gradients into ONE zeroed fp32 arena (``model._grad_arena``), and autograd hands those views to
+``.grad`` without copying.  ``NativeGradSync`` therefore reduces IN PLACE:
+
+  * a post-accumulate hook per parameter counts a group (one residual block; the embedding / head leftovers of a tower) down;
+  * when a group is complete its ``.grad`` tensors are merged into flat address ranges (one per block when autograd kept the arena
+    views; whatever they are otherwise -- correctness never depends on the aliasing) and each range is all-reduced (mean) on a
+    communication stream that waits for the streams the backward runs on: the collectives of block *i* run under the backward of
+    blocks *i-1 ...*, in reverse layer order, as DDP's buckets do;
+  * ``finish()`` (call before ``optimizer.step()``) reduces what is left (0-d parameters such as ``logit_scale``; groups that did not
+    complete because a parameter got no gradient) and makes the current stream wait for the communication stream.
+
+Transport: ``comm`` = an ``open_clip_amd.comm.NativeComm`` (RCCL through the C ABI, ``ocn_comm_allreduce_avg``) or, without it, the
+default ``torch.distributed`` process group (sum + scale; what the two-ranks-on-one-GPU / CPU gloo tests use).  Gradient averaging
+(sum / world_size) and the initial rank-0 parameter broadcast follow DDP's semantics.
+
+Unmeasured on more than one GPU (no multi-GPU node was available to the builder); on one GPU it costs the hooks only.
+"""
+import re
+from contextlib import contextmanager
+
+import torch
+
+_BLOCK = re.compile(r"^(.*resblocks\.\d+)\.")
+
+
+def _group_key(name: str) -> str:
+    m = _BLOCK.match(name)
+    if m:
+        return m.group(1)
+    return "visual.*" if name.startswith("visual.") else "text.*"
+
+
+def flat_ranges(tensors):
+    """merge tensors into maximal address-contiguous flat views: [(flat_tensor, [members])].  Contiguous fp32 tensors that sit back to
+    back in ONE storage (the views of a block's gradient arena) become one range; everything else is a range of its own.  The ranges
+    come out in the order of their first member in ``tensors`` -- NOT in address order, which differs from rank to rank while every
+    rank has to issue the same collectives in the same order."""
+    items = []
+    for pos, t in enumerate(tensors):
+        if t.is_contiguous() and t.dtype == torch.float32 and t.numel() > 0:
+            items.append((t.untyped_storage().data_ptr(), t.data_ptr(), pos, t))
+        else:
+            items.append((None, id(t), pos, t))
+    items.sort(key=lambda it: (it[0] is None, it[0] or 0, it[1]))
+    out, i = [], 0
+    while i < len(items):
+        base, ptr, pos, t = items[i]
+        if base is None:
+            out.append((pos, t, [t]))
+            i += 1
+            continue
+        members, first, end, j = [t], pos, ptr + t.numel() * 4, i + 1
+        while j < len(items) and items[j][0] == base and items[j][1] == end:
+            members.append(items[j][3])
+            first = min(first, items[j][2])
+            end += items[j][3].numel() * 4
+            j += 1
+        if len(members) == 1:
+            out.append((first, t.view(-1), members))
+        else:
+            n = (end - ptr) // 4
+            flat = torch.empty(0, dtype=torch.float32, device=t.device).set_(t.untyped_storage(), (ptr - base) // 4, (n,), (1,))
+            out.append((first, flat, members))
+        i = j
+    out.sort(key=lambda r: r[0])
+    return [(flat, members) for _, flat, members in out]
+
+
+class NativeGradSync:
+    def __init__(self, model, world_size: int, comm=None, process_group=None, broadcast_parameters: bool = True):
+        self.model, self.world_size, self.comm, self.pg = model, int(world_size), comm, process_group
+        self.enabled = True
+        self.stats = {"collectives": 0, "elements": 0, "ranges_per_group": []}
+        self._stream = None
+        self._groups, self._of = {}, {}
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            key = _group_key(name) if p.dim() > 0 else "scalars"  # 0-d parameters are reduced together in finish()
+            self._groups.setdefault(key, []).append(p)
+            self._of[p] = key
+        self._pending = {}
+        self._fired = {}
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self._of]
+        if broadcast_parameters and self.world_size > 1:
+            self.broadcast_parameters()
+
+    # ---- transport -------------------------------------------------------------------------------------------------------
+    def _allreduce_mean(self, flat):
+        if self.world_size == 1 and self.comm is None:
+            return
+        if self.comm is not None:
+            self.comm.all_reduce_avg(flat)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+            flat.mul_(1.0 / self.world_size)
+        self.stats["collectives"] += 1
+        self.stats["elements"] += flat.numel()
+
+    def broadcast_parameters(self):
+        """every rank starts from rank 0's parameters and buffers (DDP does this at construction, base_task.py:227)"""
+        import torch.distributed as dist
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                if self.comm is not None:
+                    if self.comm.rank != 0:
+                        t.zero_()
+                    self.comm.all_reduce_sum(t.data if t.is_contiguous() else t.data.contiguous())
+                else:
+                    dist.broadcast(t.data, src=0, group=self.pg)
+        if hasattr(self.model, "invalidate_weight_caches"):
+            self.model.invalidate_weight_caches()
+
+    # ---- streams ---------------------------------------------------------------------------------------------------------
+    def _comm_stream(self, dev):
+        if dev.type != "cuda":
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        return self._stream
+
+    def _reduce(self, grads):
+        dev = grads[0].device
+        cs = self._comm_stream(dev)
+        ranges = flat_ranges(grads)
+        self.stats["ranges_per_group"].append(len(ranges))
+        if cs is None:
+            for flat, _ in ranges:
+                self._allreduce_mean(flat)
+            return
+        from .model import _TOWER_SIDE
+        cs.wait_stream(torch.cuda.current_stream(dev))      # the stream the hook (and the producing backward) runs on
+        side = _TOWER_SIDE.get(dev)
+        if side is not None:
+            cs.wait_stream(side)                            # the image tower's backward, when the towers run on two streams
+        with torch.cuda.stream(cs):
+            for flat, members in ranges:
+                self._allreduce_mean(flat)
+                for m in members:
+                    m.record_stream(cs)
+
+    # ---- hooks -----------------------------------------------------------------------------------------------------------
+    def _hook(self, p):
+        if not self.enabled:
+            return
+        key = self._of[p]
+        fired = self._fired.setdefault(key, [])
+        fired.append(p)
+        if key != "scalars" and len(fired) == len(self._groups[key]):
+            self._fired[key] = []
+            self._reduce([q.grad for q in self._groups[key]])  # registration order: the same on every rank
+
+    @contextmanager
+    def no_sync(self):
+        """gradient accumulation (train.py:236-311): the micro-batches before the last one only accumulate into ``.grad``"""
+        old, self.enabled = self.enabled, False
+        try:
+            yield
+        finally:
+            self.enabled = old
+
+    def finish(self):
+        """reduce what the hooks have not (0-d parameters packed into one tensor; incomplete groups), then order the current stream
+        behind the communication stream.  Call once per optimizer step, after the last backward."""
+        left = []
+        for key in self._groups:  # registration order, not hook order
+            fired = self._fired.get(key) or []
+            left += [q for q in self._groups[key] if q.grad is not None and any(q is f for f in fired)]
+            self._fired[key] = []
+        scalars = [q for q in left if q.dim() == 0]
+        rest = [q.grad for q in left if q.dim() > 0]
+        if rest:
+            self._reduce(rest)
+        if scalars:
+            packed = torch.stack([q.grad.reshape(()).float() for q in scalars])
+            self._reduce([packed])
+            dev = packed.device
+            cs = self._comm_stream(dev)
+            ctx = torch.cuda.stream(cs) if cs is not None else _null()
+            with ctx:
+                for i, q in enumerate(scalars):
+                    q.grad.copy_(packed[i].to(q.grad.dtype))
+        if self._stream is not None:
+            torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+@contextmanager
+def _null():
+    yield

@@ -20,10 +20,59 @@ PyTorch is plumbing here (pinned allocations, streams, events); there is no arit
 import torch
 
 
+class HostTextPlan:
+    """The packed layout of one text batch (``model._TextPack``: only the tokens up to the pooled EOT exist in the text tower) computed on
+    the HOST, where the tokens come from anyway (the tokenizer's output in the loader), so that the step never has to read the packed row
+    count back from the device: index plumbing only (argmax / cumsum / a stable sort of B small integers), the tensors travel with the batch.
+    ``device_views()`` are views of ONE int32 buffer + the packed token ids."""
+
+    def __init__(self, text_host: torch.Tensor, vocab_size=None, buckets=True):
+        B, L = text_host.shape
+        eot = text_host.argmax(dim=-1)  # first maximum, as torch.argmax on the device (transformer.py:941-944)
+        lens = eot + 1
+        seq_off = torch.zeros(B + 1, dtype=torch.int64)
+        seq_off[1:] = lens.cumsum(0)
+        self.B, self.L, self.M = B, L, int(seq_off[-1])
+        self.n_bad = int(((text_host < 0) | (text_host >= vocab_size)).sum()) if vocab_size is not None else 0
+        keep = torch.arange(L)[None, :] < lens[:, None]
+        self.tokens = text_host[keep]                                  # [M] int64
+        posidx = torch.arange(L, dtype=torch.int32).expand(B, L)[keep]  # [M] int32
+        nbk = (L + 31) // 32
+        if buckets:
+            nb = (lens + 31) // 32
+            order = torch.sort(nb, stable=True).indices
+            self.counts = torch.bincount(nb - 1, minlength=nbk).tolist()
+        else:
+            order, self.counts = torch.zeros(0, dtype=torch.int64), None
+        # one int32 image: eot [B] | seq_off [B+1] | last_row [B] | order [B or 0] | posidx [M]
+        self.ints = torch.cat([eot.int(), seq_off.int(), (seq_off[1:] - 1).int(), order.int(), posidx])
+        self.has_order = bool(buckets)
+
+    @staticmethod
+    def capacity(B, L):
+        return 4 * B + 1 + B * L
+
+    def device_views(self, ints_dev, tokens_dev):
+        B, M = self.B, self.M
+        o = 0
+        eot = ints_dev[o:o + B]; o += B
+        seq_off = ints_dev[o:o + B + 1]; o += B + 1
+        last_row = ints_dev[o:o + B]; o += B
+        order = None
+        if self.has_order:
+            order = ints_dev[o:o + B]; o += B
+        posidx = ints_dev[o:o + M]
+        return {"eot": eot, "seq_off": seq_off, "last_row": last_row, "order": order, "posidx": posidx, "tokens": tokens_dev[:M],
+                "M": M, "counts": self.counts, "n_bad": self.n_bad}
+
+
 class DeviceBatchPipeline:
-    def __init__(self, device, image_shape, text_shape, depth: int = 2, image_dtype=torch.uint8):
+    def __init__(self, device, image_shape, text_shape, depth: int = 2, image_dtype=torch.uint8, plan_text_vocab=None, attn_buckets=True):
+        """``plan_text_vocab`` = the model's vocab_size: every submitted batch also carries its packed text layout computed on the host
+        (``HostTextPlan``), attached to the device text tensor; ``NativeCLIP`` then runs the step without any host synchronisation."""
         self.device = torch.device(device)
         self.depth = depth
+        self.plan_text_vocab, self.attn_buckets = plan_text_vocab, attn_buckets
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.slots = []
         for _ in range(depth):
@@ -32,8 +81,13 @@ class DeviceBatchPipeline:
                 "text": torch.empty(text_shape, dtype=torch.int64, device=self.device),
                 "h_image": torch.empty(image_shape, dtype=image_dtype).pin_memory(),
                 "h_text": torch.empty(text_shape, dtype=torch.int64).pin_memory(),
-                "ready": torch.cuda.Event(), "free": torch.cuda.Event(), "host_done": None,
+                "ready": torch.cuda.Event(), "free": torch.cuda.Event(), "host_done": None, "plan": None,
             })
+            if plan_text_vocab is not None:
+                cap = HostTextPlan.capacity(*text_shape)
+                self.slots[-1].update(plan_ints=torch.empty(cap, dtype=torch.int32, device=self.device), h_plan_ints=torch.empty(cap, dtype=torch.int32).pin_memory(),
+                                      plan_tokens=torch.empty(text_shape[0] * text_shape[1], dtype=torch.int64, device=self.device),
+                                      h_plan_tokens=torch.empty(text_shape[0] * text_shape[1], dtype=torch.int64).pin_memory())
         self._w = 0      # next slot to fill
         self._r = 0      # next slot to hand out
         self._queued = 0
@@ -42,7 +96,7 @@ class DeviceBatchPipeline:
         """the pinned host buffers of the slot the next ``submit`` will use -- a loader can decode straight into them and
         then call ``submit()`` without arguments (no extra host copy)"""
         s = self.slots[self._w]
-        if s["host_done"] is not None:
+        if s["host_done"] is not None and not s["host_done"].query():
             s["host_done"].synchronize()  # the previous transfer out of this pinned buffer has finished
         return s["h_image"], s["h_text"]
 
@@ -60,10 +114,22 @@ class DeviceBatchPipeline:
                 hi, ht = self.staging()
                 hi.copy_(image_host)
                 ht.copy_(text_host)
+        plan = None
+        if self.plan_text_vocab is not None:
+            if s["host_done"] is not None and not s["host_done"].query():
+                s["host_done"].synchronize()  # the slot's PREVIOUS transfer (``depth`` batches ago) still reads the pinned plan buffers: rare
+            plan = HostTextPlan(src_t, self.plan_text_vocab, self.attn_buckets)
+            s["h_plan_ints"][:plan.ints.numel()].copy_(plan.ints)
+            s["h_plan_tokens"][:plan.M].copy_(plan.tokens)
+        s["plan"] = plan
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(s["free"])  # the forward that read this slot last has consumed it
             s["image"].copy_(src_i, non_blocking=True)
             s["text"].copy_(src_t, non_blocking=True)
+            if plan is not None:
+                n = plan.ints.numel()
+                s["plan_ints"][:n].copy_(s["h_plan_ints"][:n], non_blocking=True)
+                s["plan_tokens"][:plan.M].copy_(s["h_plan_tokens"][:plan.M], non_blocking=True)
             s["ready"].record(self.copy_stream)
             s["host_done"] = s["ready"]
         self._w = (self._w + 1) % self.depth
@@ -78,7 +144,11 @@ class DeviceBatchPipeline:
         torch.cuda.current_stream(self.device).wait_event(s["ready"])
         self._r = (self._r + 1) % self.depth
         self._queued -= 1
-        return {"image": s["image"], "text": s["text"], "_slot": s}
+        text = s["text"]
+        if s["plan"] is not None:  # rides on the tensor object (prepare_batch leaves a device int64 tensor as it is): model._TextPack picks it up
+            text = s["text"].view(s["text"].shape)
+            text._ocn_host_plan = s["plan"].device_views(s["plan_ints"], s["plan_tokens"])
+        return {"image": s["image"], "text": text, "_slot": s}
 
     def release(self, batch):
         """call once the kernels that read ``batch`` have been enqueued (after the forward; the image is only read by the patch

@@ -432,14 +432,27 @@ class _TextPack:
     in the text tower.  The reference pools ``x[b, text[b].argmax()]`` (transformer.py:941-944) behind a causal mask (:1716-1722),
     so the positions after the pooled one influence neither the feature nor any gradient -- dropping them changes no result and
     removes their share of every GEMM / LayerNorm / attention launch of the tower (tokenizer output is ~60 % padding on LAION-like
-    captions).  ``plan()`` enqueues the two planning kernels and the 4-byte device -> host copy of the packed row count; ``finish()``
+    captions).  The constructor enqueues the planning kernels and the few-byte device -> host copy of the packed row count; ``finish()``
     waits for that copy (the only host synchronisation of the step; it is issued BEFORE the image tower so that it never drains
-    the queue) and builds the packed token / position lists."""
+    the queue) and builds the packed token / position lists.  A batch that arrives through ``DeviceBatchPipeline(plan_text_vocab=...)``
+    carries the whole layout, computed on the host next to the tokenizer: then nothing is planned or read back here (``host_planned``)
+    and the training step runs without a single host synchronisation."""
 
     def __init__(self, text, vocab_size=None, buckets=True):
+        host = getattr(text, "_ocn_host_plan", None)
         self.text = text = text.contiguous()
         self.B, self.L = text.shape
         self.vocab_size = vocab_size
+        self.host_planned = host is not None
+        if host is not None:
+            # the layout came with the batch (input_pipeline.HostTextPlan: computed on the host, where the tokens were produced): no kernel,
+            # no read-back, no host synchronisation anywhere in the step
+            if vocab_size is not None and host["n_bad"]:
+                raise IndexError(f"index out of range in self: {host['n_bad']} token id(s) outside [0, {vocab_size}) (token_embedding has {vocab_size} rows)")
+            self.eot, self.seq_off, self.last_row, self.order = host["eot"], host["seq_off"], host["last_row"], host["order"]
+            self.M, self.tokens, self.posidx = host["M"], host["tokens"], host["posidx"]
+            self.layout = ops.SeqLayout(self.seq_off, self.order, host["counts"]) if (buckets and self.order is not None) else self.seq_off
+            return
         # with the vocabulary size the plan also counts ids outside [0, vocab): the embedding kernels clamp them (they can never read
         # outside the table), nn.Embedding raises (model.py:399) -- so does finish(), from the same 8-byte read-back
         self.eot, plan, self.last_row, self.order = ops.seq_pack_plan(text, vocab_size, buckets=buckets)

@@ -127,9 +127,11 @@ class NativeAdamW(torch.optim.Optimizer):
             chunks.append(c)
             copies.append((n16, t16))
         chunks = np.concatenate(chunks, axis=0)
-        plan = {"entries": ent, "n_chunks": int(chunks.shape[0]), "copies": copies, "copied": None,
+        # the record table travels host -> device every step through one of TWO pinned buffers used alternately: the buffer a step fills
+        # was last read by the upload of two steps ago, so the wait below never blocks a host that runs a step ahead of the device
+        plan = {"entries": ent, "n_chunks": int(chunks.shape[0]), "copies": copies, "copied": [None, None], "turn": 0,
                 "chunks_dev": torch.from_numpy(chunks).to(dev),
-                "entries_host": torch.empty(len(active) * _ENTRY.itemsize, dtype=torch.uint8).pin_memory(),
+                "entries_host": [torch.empty(len(active) * _ENTRY.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)],
                 "entries_dev": torch.empty(len(active) * _ENTRY.itemsize, dtype=torch.uint8, device=dev)}
         return plan
 
@@ -146,8 +148,10 @@ class NativeAdamW(torch.optim.Optimizer):
         if key != self._plan_key:
             self._plan, self._plan_key = self._build_plan(active), key
         plan = self._plan
-        if plan["copied"] is not None:
-            plan["copied"].synchronize()  # the previous step's table upload has left the pinned buffer
+        turn = plan["turn"]
+        plan["turn"] = 1 - turn
+        if plan["copied"][turn] is not None and not plan["copied"][turn].query():
+            plan["copied"][turn].synchronize()  # the upload of two steps ago out of this pinned buffer (in practice long finished)
         ent = plan["entries"]
         b1, b2 = active[0][0]["betas"]
         eps = active[0][0]["eps"]
@@ -173,11 +177,11 @@ class NativeAdamW(torch.optim.Optimizer):
             e["lr"], e["wd"] = group["lr"], group["weight_decay"]
             e["bc1"] = 1.0 - b1 ** st["step"]
             e["bc2_sqrt"] = (1.0 - b2 ** st["step"]) ** 0.5
-        host = plan["entries_host"]
+        host = plan["entries_host"][turn]
         host.numpy()[:] = ent.view(np.uint8).reshape(-1)
         plan["entries_dev"].copy_(host, non_blocking=True)
-        plan["copied"] = torch.cuda.Event()
-        plan["copied"].record()
+        plan["copied"][turn] = torch.cuda.Event()
+        plan["copied"][turn].record()
         stream = torch.cuda.current_stream().cuda_stream
         gn, max_norm = 0, 0.0
         if self.grad_clip_norm is not None:

@@ -63,3 +63,21 @@ def test_bench_accumulation_and_host_fed_modes():
     assert h2d["config"]["input"] == "host_uint8_h2d" and math.isfinite(h2d["config"]["final_loss"]) and h2d["value"] > 0
     both = _bench(["--h2d", "--accum-freq", "2"])
     assert both["config"]["accum_freq"] == 2 and math.isfinite(both["config"]["final_loss"])
+
+
+def test_bench_native_allreduce_paths():
+    """bench.py --native-allreduce: (a) two ranks on the one GPU over gloo -- NativeGradSync instead of DistributedDataParallel -- report the
+    loss of the DDP run and of one process on the concatenated batch; (b) one process with a ONE-rank RCCL communicator behind the C ABI
+    (ocn_comm_allreduce_avg on every block's gradient arena, the loss collectives untouched) reproduces the plain one-process loss"""
+    env = {"OCN_BENCH_ONE_DEVICE": "1"}
+    ddp = _bench(["--dist-backend", "gloo"], nproc=2, env=env)
+    nat = _bench(["--dist-backend", "gloo", "--native-allreduce"], nproc=2, env=env)
+    assert nat["config"]["ddp"] is False and "native per-block" in nat["config"]["gradient_allreduce"] and ddp["config"]["ddp"] is True
+    assert abs(nat["config"]["final_loss"] - ddp["config"]["final_loss"]) < 3e-2, (nat["config"]["final_loss"], ddp["config"]["final_loss"])
+    plain = _bench([])
+    one = _bench(["--native-allreduce"])
+    assert "RCCL through the C ABI" in one["config"]["gradient_allreduce"]
+    assert abs(one["config"]["final_loss"] - plain["config"]["final_loss"]) < 3e-2
+    acc = _bench(["--native-allreduce", "--accum-freq", "2"])
+    ref = _bench(["--accum-freq", "2"])
+    assert abs(acc["config"]["final_loss"] - ref["config"]["final_loss"]) < 3e-2

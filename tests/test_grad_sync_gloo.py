@@ -1,0 +1,129 @@
+"""CPU, world_size 2 over gloo: ``NativeGradSync`` (open_clip_amd/grad_sync.py -- per-block in-place gradient all-reduce from
+post-accumulate hooks, the replacement for DistributedDataParallel's reducer, base_task.py:219-232) leaves in ``.grad`` exactly what
+DDP leaves there: the mean over ranks, for arena-backed block gradients (one collective per block), separately allocated gradients,
+0-d parameters, accumulation under ``no_sync()`` and parameters that get no gradient; and every rank starts from rank 0's weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class _ArenaBlockFn(torch.autograd.Function):
+    """y = x @ W^T + b with BOTH parameter gradients written into one flat arena, as the native residual block does"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        arena = torch.zeros(w.numel() + dy.shape[1])
+        dw, db = arena[:w.numel()].view(w.shape), arena[w.numel():]
+        dw += dy.t() @ x
+        db += dy.sum(0)
+        return dy @ w, dw, db
+
+
+class _Block(nn.Module):
+    def __init__(self, d, arena):
+        super().__init__()
+        self.fc = nn.Linear(d, d)
+        self.arena = arena
+
+    def forward(self, x):
+        if self.arena:
+            return torch.tanh(_ArenaBlockFn.apply(x, self.fc.weight, self.fc.bias))
+        return torch.tanh(self.fc(x))
+
+
+class _Toy(nn.Module):
+    def __init__(self, d=6):
+        super().__init__()
+        self.visual = nn.Module()
+        self.visual.proj = nn.Parameter(torch.randn(d, d) * 0.3)
+        self.visual.unused = nn.Parameter(torch.randn(3))  # never receives a gradient
+        self.resblocks = nn.ModuleList([_Block(d, True), _Block(d, False), _Block(d, True)])
+        self.logit_scale = nn.Parameter(torch.tensor(1.5))
+
+    def forward(self, x):
+        x = x @ self.visual.proj
+        for b in self.resblocks:
+            x = b(x)
+        return (x * self.logit_scale.exp()).pow(2).mean()
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from open_clip_amd.grad_sync import NativeGradSync
+    torch.manual_seed(100 + rank)  # DIFFERENT initial weights per rank: both wrappers must start from rank 0's
+    a, b = _Toy(), _Toy()
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator().manual_seed(7 + rank)
+    xs = [torch.randn(5, 6, generator=g) for _ in range(3)]
+    ddp = nn.parallel.DistributedDataParallel(a, find_unused_parameters=True)
+    sync = NativeGradSync(b, world, process_group=dist.new_group())  # its own group: DDP keeps asynchronous collectives in flight on the default one
+    same_start = all(torch.equal(p, q_) for p, q_ in zip(a.parameters(), b.parameters()))
+    # step 1: plain; step 2: two accumulated micro-batches (no_sync on the first)
+    ddp(xs[0]).backward()
+    b(xs[0]).backward()
+    sync.finish()
+    g1 = [(n, p.grad.numpy().copy(), dict(b.named_parameters())[n].grad.numpy().copy()) for n, p in a.named_parameters() if p.grad is not None]
+    unused_ok = b.visual.unused.grad is None
+    ddp.zero_grad(set_to_none=True)
+    b.zero_grad(set_to_none=True)
+    with ddp.no_sync():
+        ddp(xs[1]).backward()
+    ddp(xs[2]).backward()
+    with sync.no_sync():
+        b(xs[1]).backward()
+    b(xs[2]).backward()
+    sync.finish()
+    g2 = [(n, p.grad.numpy().copy(), dict(b.named_parameters())[n].grad.numpy().copy()) for n, p in a.named_parameters() if p.grad is not None]
+    q.put((rank, same_start, unused_ok, g1, g2, dict(sync.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_grad_sync_equals_ddp_over_gloo():
+    world, port = 2, 29741
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+    for rank in range(world):
+        same_start, unused_ok, g1, g2, stats = got[rank]
+        assert same_start, "rank-0 parameter broadcast missing"
+        assert unused_ok
+        for step, gs in (("step1", g1), ("accumulated", g2)):
+            for name, g_ddp, g_native in gs:
+                assert np.allclose(g_native, g_ddp, rtol=1e-6, atol=1e-8), (rank, step, name)
+        # the two arena-backed blocks went out as ONE flat range each, the module-autograd block as its two tensors
+        assert sorted(stats["ranges_per_group"][:4]) == [1, 1, 1, 2], stats
+    # ranks agree with each other
+    for (n, _, a0), (_, _, a1) in zip(got[0][2], got[1][2]):
+        assert np.array_equal(a0, a1), n
+
+
+def test_flat_ranges_merges_only_adjacent_views_of_one_storage():
+    from open_clip_amd.grad_sync import flat_ranges
+    arena = torch.arange(20, dtype=torch.float32)
+    a, b, c = arena[0:6].view(2, 3), arena[6:10], arena[12:20].view(2, 4)  # a|b adjacent, c behind a gap
+    other = torch.ones(5)
+    r = flat_ranges([c, other, b, a])
+    sizes = sorted(f.numel() for f, _ in r)
+    assert sizes == [5, 8, 10]
+    flat = [f for f, m in r if f.numel() == 10][0]
+    flat.mul_(2)  # in place through the flat view
+    assert torch.equal(a.reshape(-1), torch.arange(6, dtype=torch.float32) * 2) and float(b[-1]) == 18.0 and float(arena[10]) == 10.0
