@@ -37,7 +37,8 @@ enum ocn_epilogue {
     OCN_EPI_BIAS_GELU = 1,      /* out_bf16 = gelu(acc+bias); aux_u8 = gelu'(acc+bias) in 8-bit fixed point (for EPI 3) */
     OCN_EPI_BIAS_RESID_F32 = 2, /* out_f32 = resid_f32 + acc + bias                                       */
     OCN_EPI_DGELU = 3,          /* out_bf16 = acc * decode(aux_u8)   (aux = the gelu' saved by EPI 1)      */
-    OCN_EPI_F32 = 4             /* out_f32 = alpha*acc + bias                                             */
+    OCN_EPI_F32 = 4,            /* out_f32 = alpha*acc + bias                                             */
+    OCN_EPI_BIAS_QUICKGELU = 7  /* EPI 1 with QuickGELU, x * sigmoid(1.702 x) (layers.py:29-32; `quick_gelu` configs); (5, 6: internal) */
 };
 
 const char* ocn_last_error(void);

@@ -15,6 +15,13 @@ _MODEL_CONFIGS = {
         "vision_cfg": {"image_size": 224, "layers": 12, "width": 768, "patch_size": 32},
         "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": 512, "heads": 8, "layers": 12},
     },
+    # src/open_clip/model_configs/ViT-B-32-quickgelu.json (the OpenAI / LAION-400M ViT-B/32 checkpoints: QuickGELU in both towers)
+    "ViT-B-32-quickgelu": {
+        "embed_dim": 512,
+        "quick_gelu": True,
+        "vision_cfg": {"image_size": 224, "layers": 12, "width": 768, "patch_size": 32},
+        "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": 512, "heads": 8, "layers": 12},
+    },
     # src/open_clip/model_configs/ViT-L-14.json
     "ViT-L-14": {
         "embed_dim": 768,

@@ -31,9 +31,9 @@ OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
     const float b = a.bias ? a.bias[gn] : 0.f;
     if (EPI == OCN_EPI_BF16) {
         ((bf16*)a.out)[o] = f2bf(v * a.alpha + b);
-    } else if (EPI == OCN_EPI_BIAS_GELU) {
+    } else if (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU) {
         float g1, d1;
-        gelu_both(v + b, g1, d1);
+        act_both<EPI == OCN_EPI_BIAS_QUICKGELU>(v + b, g1, d1);
         a.aux[o] = (unsigned char)(dgelu_q_bits(d1) & 255u);
         ((bf16*)a.out)[o] = f2bf(g1);
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
@@ -100,12 +100,12 @@ OCN_DEV void epi_apply_store(const GemmNtArgs& a, int gm, int gn, f32x4 v, f32x4
     if (EPI == OCN_EPI_BF16) {
         bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
-    } else if (EPI == OCN_EPI_BIAS_GELU) {
+    } else if (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU) {
         f32x4 gv, dv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float g1, d1;
-            gelu_both(v[e], g1, d1);
+            act_both<EPI == OCN_EPI_BIAS_QUICKGELU>(v[e], g1, d1);
             gv[e] = g1;
             dv[e] = d1;
         }
@@ -445,7 +445,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)out & 15) == 0,
                   "ocn_gemm_nt: operands must be 16-byte aligned");
     OCN_CHECK_ARG(epilogue != OCN_EPI_BIAS_RESID_F32 || resid, "ocn_gemm_nt: residual epilogue needs resid");
-    OCN_CHECK_ARG((epilogue != OCN_EPI_BIAS_GELU && epilogue != OCN_EPI_DGELU) || aux, "ocn_gemm_nt: gelu epilogues need aux");
+    OCN_CHECK_ARG((epilogue != OCN_EPI_BIAS_GELU && epilogue != OCN_EPI_BIAS_QUICKGELU && epilogue != OCN_EPI_DGELU) || aux, "ocn_gemm_nt: gelu epilogues need aux");
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (unsigned char*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
@@ -454,6 +454,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     switch (epilogue) {
         case OCN_EPI_BF16: return launch_nt<OCN_EPI_BF16>(a, st);
         case OCN_EPI_BIAS_GELU: return launch_nt<OCN_EPI_BIAS_GELU>(a, st);
+        case OCN_EPI_BIAS_QUICKGELU: return launch_nt<OCN_EPI_BIAS_QUICKGELU>(a, st);
         case OCN_EPI_BIAS_RESID_F32: return launch_nt<OCN_EPI_BIAS_RESID_F32>(a, st);
         case OCN_EPI_DGELU: return launch_nt<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch_nt<OCN_EPI_F32>(a, st);

@@ -91,12 +91,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const int gn_w = n0 + wn * 64;
     const int rd_row = lane_o >> 3, rd_chunk = lane_o & 7;
     const unsigned rd_addr = stg + rd_row * 128 + ((rd_chunk ^ rd_row) << 4);  // + it * 1024 for rows it*8 + rd_row
-    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_CE_GRAD);
+    constexpr bool IS_GELU = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);  // two-output activation epilogues
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || EPI == OCN_EPI_CE_GRAD);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     // developer knobs 32 / 128: zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued but the
     // bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
     const int m_st = (a.ablate & 32) ? 0 : a.M, m_ld = (a.ablate & 128) ? 0 : a.M;
-    const bool aux_is_out = (EPI == OCN_EPI_BIAS_GELU);
+    const bool aux_is_out = IS_GELU;
     // developer knob 0x80000: every store of this workgroup lands in ONE 64 KiB window (per workgroup, at the head of the output) that
     // stays resident in L2 -- the stores are issued and acknowledged as usual but never have to wait for HBM: what the tile loop would
     // cost if no operand wait ever sat behind a store acknowledgement (profiles/r02_nt6_trickled_epilogue_experiment.txt, finding (a))
@@ -210,13 +211,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
                         if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else if (EPI != OCN_EPI_CE_GRAD) v = v + bv[hb][g];
-                        if (EPI == OCN_EPI_BIAS_GELU) {
+                        if (IS_GELU) {
                             f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
                             if (!(a.ablate & 1)) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     float g1, d1;
-                                    gelu_both(v[e], g1, d1);
+                                    act_both<EPI == OCN_EPI_BIAS_QUICKGELU>(v[e], g1, d1);
                                     gv[e] = g1;
                                     dv[e] = d1;
                                 }
@@ -226,7 +227,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         }
                         pk[hb][g] = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     }
-                if constexpr (EPI == OCN_EPI_BIAS_GELU) {
+                if constexpr (IS_GELU) {
                     if (dbg && ha == 1 && s == 0) dbg[6] = wall_clock64();
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb)
@@ -242,7 +243,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     }
                 }
                 {
-                    if (dbg && ha == 1 && s == 0 && EPI != OCN_EPI_BIAS_GELU) dbg[6] = wall_clock64();
+                    if (dbg && ha == 1 && s == 0 && !IS_GELU) dbg[6] = wall_clock64();
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -647,7 +648,7 @@ template <int EPI>
 int nt5_stagger(int ntiles, int K, int forced) {
     if (forced == 63) return 0;
     if (forced > 0) return forced * 100;
-    constexpr bool heavy = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
+    constexpr bool heavy = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU || EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     if (!heavy || ntiles < 12 * g_num_cu) return 0;
     const int tile_us = (K / 64) * 2 + 6;
     return tile_us * 100 / 4;
@@ -691,7 +692,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     //   stores: non-temporal for the GELU epilogue and for wide bf16 outputs (N >= 1024: the QKV projections, +4..6 %);
     //   loads:  non-temporal for the fp32 residual, which is read exactly once (+1..3 %); the saved GELU derivative of the dGELU
     //           epilogue is better left cacheable (-5 % otherwise).
-    const bool st_nt = (EPI == OCN_EPI_BIAS_GELU) || (EPI == OCN_EPI_BF16 && a.N >= 1024);
+    const bool st_nt = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU) || (EPI == OCN_EPI_BF16 && a.N >= 1024);
     const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32);
     // bit 5 (32): deep operand ring of the dGELU / fp32-residual epilogues (see epilogue5); developer knob 0x100000 flips it
     constexpr bool has_ex = (EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32);
@@ -742,6 +743,7 @@ int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
     switch (epilogue) {
         case OCN_EPI_BF16: return launch5<OCN_EPI_BF16>(a, st);
         case OCN_EPI_BIAS_GELU: return launch5<OCN_EPI_BIAS_GELU>(a, st);
+        case OCN_EPI_BIAS_QUICKGELU: return launch5<OCN_EPI_BIAS_QUICKGELU>(a, st);
         case OCN_EPI_BIAS_RESID_F32: return launch5<OCN_EPI_BIAS_RESID_F32>(a, st);
         case OCN_EPI_DGELU: return launch5<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch5<OCN_EPI_F32>(a, st);

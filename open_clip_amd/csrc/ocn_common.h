@@ -113,6 +113,19 @@ OCN_DEV f32x4 dgelu_unpack4(unsigned q) {
     return (f32x4){dgelu_unq(q & 255u), dgelu_unq((q >> 8) & 255u), dgelu_unq((q >> 16) & 255u), dgelu_unq(q >> 24)};
 }
 
+// QuickGELU (reference layers.py:29-32: x * sigmoid(1.702 x); the OpenAI / LAION-400M checkpoints were trained with it) and its derivative
+// s + 1.702 x s (1 - s), which lies in [-0.099, 1.099]: inside the 8-bit code range of the saved derivative above
+OCN_DEV void quickgelu_both(float x, float& g, float& dg) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+    g = x * s;
+    dg = fmaf(1.702f * g, 1.0f - s, s);
+}
+// activation of an epilogue: gelu_both for OCN_EPI_BIAS_GELU, quickgelu_both for OCN_EPI_BIAS_QUICKGELU
+template <bool QUICK>
+OCN_DEV void act_both(float x, float& g, float& dg) {
+    if (QUICK) quickgelu_both(x, g, dg); else gelu_both(x, g, dg);
+}
+
 OCN_DEV float dgelu_f(float x) {
     float cdf, e;
     gelu_parts(x, cdf, e);

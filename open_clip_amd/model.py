@@ -190,7 +190,7 @@ def _grad_arena(p):
     return grads
 
 
-def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
+def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None, act=ops.EPI_BIAS_GELU):
     (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
     M, C = x.shape
     h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
@@ -201,7 +201,7 @@ def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
     h2, _, mean2, rstd2 = ops.layernorm_fwd(xmid, ln2w, ln2b)
     Fd = wfc.shape[0]
     f = ops.empty((M, Fd), torch.uint8, x)  # gelu'(pre-activation) in 8-bit fixed point: all the backward needs of it
-    g = ops.gemm_nt(ops.EPI_BIAS_GELU, h2, cache.get(wfc, "n"), ops.empty((M, Fd), BF16, x), bias=bfc, aux=f)
+    g = ops.gemm_nt(act, h2, cache.get(wfc, "n"), ops.empty((M, Fd), BF16, x), bias=bfc, aux=f)  # act: erf GELU or QuickGELU epilogue
     y = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g, cache.get(wproj, "n"), ops.empty((M, C), F32, x), bias=bproj, resid=xmid)
     return y, (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g)
 
@@ -209,10 +209,10 @@ def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None):
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, cache, B, L, heads, causal, recompute,
-                seq_off=None):
+                seq_off=None, act=ops.EPI_BIAS_GELU):
         p = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj)
-        y, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off)
-        ctx.meta = (cache, B, L, heads, causal, recompute, seq_off)
+        y, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off, act)
+        ctx.meta = (cache, B, L, heads, causal, recompute, seq_off, act)
         if recompute:  # block-granular activation recompute (transformer.py:579-581): keep only the block input
             ctx.save_for_backward(x, *p)
         else:
@@ -221,12 +221,12 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        cache, B, L, heads, causal, recompute, seq_off = ctx.meta
+        cache, B, L, heads, causal, recompute, seq_off, act = ctx.meta
         t = ctx.saved_tensors
         x, p = t[0], t[1:13]
         (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
         if recompute:
-            _, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off)
+            _, saved = _block_forward(x, p, cache, B, L, heads, causal, seq_off, act)
         else:
             saved = t[13:]
         (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g) = saved
@@ -268,7 +268,7 @@ class _BlockFn(torch.autograd.Function):
         _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
-        return (dx, *grads, None, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -281,7 +281,7 @@ class _BlockFn(torch.autograd.Function):
 # (tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); ``model.pooled_last_block = False`` (a constructor argument, too) runs
 # the full block.  `rows` = absolute row of each sequence's pooled token (int32 [B]); the output is [B, C].
 # ------------------------------------------------------------------------------------------------------
-def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None):
+def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None, act=ops.EPI_BIAS_GELU):
     (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
     M, C = x.shape
     h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
@@ -294,7 +294,7 @@ def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None):
     h2_p, _, mean2, rstd2 = ops.layernorm_fwd(xmid_p, ln2w, ln2b)
     Fd = wfc.shape[0]
     f_p = ops.empty((B, Fd), torch.uint8, x)
-    g_p = ops.gemm_nt(ops.EPI_BIAS_GELU, h2_p, cache.get(wfc, "n"), ops.empty((B, Fd), BF16, x), bias=bfc, aux=f_p)
+    g_p = ops.gemm_nt(act, h2_p, cache.get(wfc, "n"), ops.empty((B, Fd), BF16, x), bias=bfc, aux=f_p)
     y_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g_p, cache.get(wproj, "n"), ops.empty((B, C), F32, x), bias=bproj, resid=xmid_p)
     return y_p, (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p)
 
@@ -302,10 +302,10 @@ def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None):
 class _PooledBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj, rows, cache, B, L, heads, causal, recompute,
-                seq_off=None):
+                seq_off=None, act=ops.EPI_BIAS_GELU):
         p = (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj)
-        y_p, saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off)
-        ctx.meta = (cache, B, L, heads, causal, recompute, seq_off)
+        y_p, saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off, act)
+        ctx.meta = (cache, B, L, heads, causal, recompute, seq_off, act)
         if recompute:
             ctx.save_for_backward(x, *p, rows)
         else:
@@ -314,11 +314,11 @@ class _PooledBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy_p):
-        cache, B, L, heads, causal, recompute, seq_off = ctx.meta
+        cache, B, L, heads, causal, recompute, seq_off, act = ctx.meta
         t = ctx.saved_tensors
         x, p, rows = t[0], t[1:13], t[13]
         (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
-        saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off)[1] if recompute else t[14:]
+        saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off, act)[1] if recompute else t[14:]
         (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p) = saved
         M, C = x.shape
         Fd = wfc.shape[0]
@@ -350,7 +350,7 @@ class _PooledBlockFn(torch.autograd.Function):
         _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
-        return (dx, *grads, None, None, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -562,13 +562,15 @@ class Mlp(_Params):  # transformer.py:295-299 (OrderedDict c_fc / gelu / c_proj)
 
 
 class ResidualAttentionBlock(nn.Module):  # transformer.py:274-330
-    def __init__(self, d_model, n_head, mlp_ratio=4.0):
+    def __init__(self, d_model, n_head, mlp_ratio=4.0, quick_gelu=False):
         super().__init__()
         self.ln_1 = LayerNorm(d_model)
         self.attn = Attention(d_model, n_head)
         self.ln_2 = LayerNorm(d_model)
         self.mlp = Mlp(d_model, int(d_model * mlp_ratio))
         self.n_head = n_head
+        # act_layer of the MLP (transformer.py:295-299): nn.GELU (erf), or QuickGELU for the `quick_gelu` configs (model.py:172, layers.py:29-32)
+        self.act_epilogue = ops.EPI_BIAS_QUICKGELU if quick_gelu else ops.EPI_BIAS_GELU
 
     def params(self):
         return (self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight, self.attn.in_proj_bias,
@@ -583,15 +585,15 @@ class ResidualAttentionBlock(nn.Module):  # transformer.py:274-330
         then runs on them alone and the result is [B, C] (_PooledBlockFn).  Both forms go through ``Module.__call__``, so forward /
         forward-pre hooks on the block (FSDP2's unshard, feature extraction, profilers) fire either way."""
         if pooled_rows is not None:
-            return _PooledBlockFn.apply(x, *self.params(), pooled_rows, cache, B, L, self.n_head, causal, recompute, seq_off)
-        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute, seq_off)
+            return _PooledBlockFn.apply(x, *self.params(), pooled_rows, cache, B, L, self.n_head, causal, recompute, seq_off, self.act_epilogue)
+        return _BlockFn.apply(x, *self.params(), cache, B, L, self.n_head, causal, recompute, seq_off, self.act_epilogue)
 
 
 class Transformer(nn.Module):  # transformer.py:476-585
-    def __init__(self, width, layers, heads, mlp_ratio=4.0):
+    def __init__(self, width, layers, heads, mlp_ratio=4.0, quick_gelu=False):
         super().__init__()
         self.width, self.layers = width, layers
-        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads, mlp_ratio) for _ in range(layers)])
+        self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads, mlp_ratio, quick_gelu) for _ in range(layers)])
         self.grad_checkpointing = False
 
     def get_cast_dtype(self):  # transformer.py:537-538
@@ -650,7 +652,7 @@ class _Embedding(_Params):
 
 
 class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: learnable pos, 'tok' pool, no patch dropout)
-    def __init__(self, image_size, patch_size, width, layers, heads, mlp_ratio, output_dim):
+    def __init__(self, image_size, patch_size, width, layers, heads, mlp_ratio, output_dim, quick_gelu=False):
         super().__init__()
         self.image_size = (image_size, image_size)
         self.patch_size = (patch_size, patch_size)
@@ -663,7 +665,7 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         self.class_embedding = nn.Parameter(scale * torch.randn(width))
         self.positional_embedding = nn.Parameter(scale * torch.randn(self.grid_size[0] * self.grid_size[1] + 1, width))
         self.ln_pre = LayerNorm(width)
-        self.transformer = Transformer(width, layers, heads, mlp_ratio)
+        self.transformer = Transformer(width, layers, heads, mlp_ratio, quick_gelu)
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self._cache = _WeightCache()
@@ -735,7 +737,7 @@ class NativeCLIP(nn.Module):
                       "proj_bias": False, "proj_type": "linear", "output_tokens": False, "act_kwargs": None, "norm_kwargs": None, "block_type": None,
                       "qk_norm": False, "scaled_cosine_attn": False, "scale_heads": False, "scale_attn_inner": False, "scale_attn": False,
                       "scale_fc": False, "mlp_type": "mlp", "hf_proj_type": None, "hf_pooler_type": None}
-    _MODEL_DEFAULTS = {"quick_gelu": False, "force_quick_gelu": False, "cast_dtype": None, "nonscalar_logit_scale": False, "custom_text": False,
+    _MODEL_DEFAULTS = {"cast_dtype": None, "nonscalar_logit_scale": False, "custom_text": False,
                        "multimodal_cfg": None}
 
     @classmethod
@@ -752,7 +754,7 @@ class NativeCLIP(nn.Module):
 
     def __init__(self, embed_dim, vision_cfg, text_cfg, init_logit_scale=math.log(1 / 0.07), init_logit_bias=None,
                  output_dict=False, *, pack_text=True, tower_streams=True, pooled_last_block=True, attn_buckets=True, pair_wgrad=True,
-                 deterministic=False, **model_kwargs):
+                 deterministic=False, quick_gelu=False, **model_kwargs):
         """Reference arguments first (model.py:318-365).  Keyword-only switches of the native execution (every one also a plain attribute
         that may be flipped later; none changes a result beyond fp32 summation order):
         ``pack_text`` -- the text tower holds only the tokens up to the pooled EOT (_TextPack); ``tower_streams`` -- image tower on a
@@ -771,10 +773,13 @@ class NativeCLIP(nn.Module):
         for hd in (head_width, t["width"] // t["heads"]):
             if hd not in (64, 80, 96, 128):
                 raise NotImplementedError(f"the native attention kernels support head_dim 64 / 80 / 96 / 128 (got {hd})")
+        # `quick_gelu` (model.py:172-176, :262): QuickGELU instead of nn.GELU in the MLPs of BOTH towers (ViT-B-32-quickgelu.json: the
+        # OpenAI / LAION-400M checkpoints)
+        self.quick_gelu = bool(quick_gelu)
         self.visual = VisionTransformer(v["image_size"], v["patch_size"], v["width"], v["layers"], v["width"] // head_width,
-                                        v.get("mlp_ratio", 4.0), embed_dim)
+                                        v.get("mlp_ratio", 4.0), embed_dim, self.quick_gelu)
         tw = t["width"]
-        self.transformer = Transformer(tw, t["layers"], t["heads"], t.get("mlp_ratio", 4.0))
+        self.transformer = Transformer(tw, t["layers"], t["heads"], t.get("mlp_ratio", 4.0), self.quick_gelu)
         self.context_length = t["context_length"]
         self.vocab_size = t["vocab_size"]
         self.token_embedding = _Embedding(self.vocab_size, tw)
@@ -965,7 +970,7 @@ def convert_to_custom_text_state_dict(state_dict: dict) -> dict:
 
 
 def create_model(model_name: str, pretrained: Optional[str] = None, precision: str = "amp_bf16", device="cuda",
-                 output_dict: Optional[bool] = None, init_logit_scale=None, init_logit_bias=None, **model_kwargs):
+                 output_dict: Optional[bool] = None, init_logit_scale=None, init_logit_bias=None, force_quick_gelu: bool = False, **model_kwargs):
     """Counterpart of ``open_clip.factory.create_model`` (factory.py:264-287) for the native path.
     ``pretrained`` may be a local ``.pt`` state-dict path (no hub access); ``precision`` must be an
     amp_bf16-equivalent mode (the kernels implement exactly that policy)."""
@@ -992,6 +997,8 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     if init_logit_bias is not None:
         kw["init_logit_bias"] = init_logit_bias
     kw = {k: v for k, v in kw.items() if v is not None}
+    if force_quick_gelu:  # factory.py:521-523: override for checkpoints trained with QuickGELU
+        extra_model_kwargs["quick_gelu"] = True
     out_dict = output_dict if output_dict is not None else cfg_output_dict
     model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=bool(out_dict), **kw, **extra_model_kwargs)
     if pretrained:

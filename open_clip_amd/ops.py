@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID_F32, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
+EPI_BIAS_QUICKGELU = 7  # EPI_BIAS_GELU with x * sigmoid(1.702 x) (layers.py:29-32); its backward is the same EPI_DGELU
 BF16, F32 = torch.bfloat16, torch.float32
 
 

@@ -40,6 +40,11 @@ def gelu_erf(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
+def quick_gelu(x: Tensor) -> Tensor:
+    """layers.py:29-32 (``QuickGELU``): x * sigmoid(1.702 x); selected by ``quick_gelu`` in the model config (model.py:172-176, :262)."""
+    return x * (1.0 / (1.0 + torch.exp(-1.702 * x)))
+
+
 def attention(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int, causal: bool) -> Tensor:
     """transformer.py:157-248 (``Attention.forward``, self-attention fast path).
 
@@ -65,20 +70,20 @@ def attention(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int, causal: boo
     return o @ p[pre + "attn.out_proj.weight"].t() + p[pre + "attn.out_proj.bias"]
 
 
-def resblock(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int, causal: bool) -> Tensor:
+def resblock(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int, causal: bool, quick: bool = False) -> Tensor:
     """transformer.py:319-330 (``ResidualAttentionBlock.forward``; ls_1/ls_2 = Identity)."""
     x = x + attention(layer_norm(x, p[pre + "ln_1.weight"], p[pre + "ln_1.bias"]), p, pre, heads, causal)
     h = layer_norm(x, p[pre + "ln_2.weight"], p[pre + "ln_2.bias"])
     h = h @ p[pre + "mlp.c_fc.weight"].t() + p[pre + "mlp.c_fc.bias"]
-    h = gelu_erf(h)
+    h = quick_gelu(h) if quick else gelu_erf(h)
     h = h @ p[pre + "mlp.c_proj.weight"].t() + p[pre + "mlp.c_proj.bias"]
     return x + h
 
 
-def transformer(x: Tensor, p: Dict[str, Tensor], pre: str, layers: int, heads: int, causal: bool) -> Tensor:
+def transformer(x: Tensor, p: Dict[str, Tensor], pre: str, layers: int, heads: int, causal: bool, quick: bool = False) -> Tensor:
     """transformer.py:577-585 (``Transformer.forward``: for r in resblocks)."""
     for i in range(layers):
-        x = resblock(x, p, f"{pre}resblocks.{i}.", heads, causal)
+        x = resblock(x, p, f"{pre}resblocks.{i}.", heads, causal, quick)
     return x
 
 
@@ -109,7 +114,7 @@ def encode_image(image: Tensor, p: Dict[str, Tensor], cfg: dict, normalize: bool
     x = torch.cat([cls, x], dim=1) + p["visual.positional_embedding"]
     x = layer_norm(x, p["visual.ln_pre.weight"], p["visual.ln_pre.bias"])
     heads = width // v.get("head_width", 64)
-    x = transformer(x, p, "visual.transformer.", v["layers"], heads, causal=False)
+    x = transformer(x, p, "visual.transformer.", v["layers"], heads, causal=False, quick=bool(cfg.get("quick_gelu", False)))
     x = layer_norm(x, p["visual.ln_post.weight"], p["visual.ln_post.bias"])
     pooled = x[:, 0] @ p["visual.proj"]
     return l2_normalize(pooled) if normalize else pooled
@@ -119,7 +124,7 @@ def encode_text(text: Tensor, p: Dict[str, Tensor], cfg: dict, normalize: bool =
     """model.py:396-411 (``CLIP._encode_text``) + transformer.py:931-954 (``text_global_pool`` 'argmax')."""
     t = cfg["text_cfg"]
     x = p["token_embedding.weight"][text] + p["positional_embedding"]
-    x = transformer(x, p, "transformer.", t["layers"], t["heads"], causal=True)
+    x = transformer(x, p, "transformer.", t["layers"], t["heads"], causal=True, quick=bool(cfg.get("quick_gelu", False)))
     x = layer_norm(x, p["ln_final.weight"], p["ln_final.bias"])
     pooled = x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ p["text_projection"]
     return l2_normalize(pooled) if normalize else pooled

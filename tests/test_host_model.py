@@ -176,8 +176,13 @@ def test_unsupported_options_fail_loudly_and_init_follows_the_reference_distribu
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.model import NativeCLIP, create_model
     cfg = get_model_config("tiny-test")
-    with pytest.raises(NotImplementedError, match="quick_gelu"):
-        NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], quick_gelu=True)
+    with pytest.raises(NotImplementedError, match="nonscalar_logit_scale"):
+        NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], nonscalar_logit_scale=True)
+    from open_clip_amd import ops
+    q = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], quick_gelu=True)  # the `*-quickgelu` configs (layers.py:29-32)
+    assert q.quick_gelu and all(b.act_epilogue == ops.EPI_BIAS_QUICKGELU for b in list(q.visual.transformer.resblocks) + list(q.transformer.resblocks))
+    assert create_model("ViT-B-32-quickgelu", device="meta").quick_gelu and not create_model("ViT-B-32", device="meta").quick_gelu
+    assert create_model("ViT-B-32", device="meta", force_quick_gelu=True).quick_gelu
     with pytest.raises(NotImplementedError, match="pool_type"):
         NativeCLIP(cfg["embed_dim"], dict(cfg["vision_cfg"], pool_type="avg"), cfg["text_cfg"])
     with pytest.raises(NotImplementedError, match="no_causal_mask"):

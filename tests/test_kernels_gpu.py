@@ -131,6 +131,25 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     check(tag + " dgelu", out, ref * ops.dgelu_decode(dsaved), bf16_out=True, abs_tol=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(400, 384, 192), (2048, 1024, 256), (37, 6, 64), (5000, 520, 128)])
+def test_gemm_nt_quickgelu_epilogue(dev, M, N, K):
+    """OCN_EPI_BIAS_QUICKGELU (layers.py:29-32: x * sigmoid(1.702 x)): output and saved derivative against torch autograd, through the
+    persistent and the general kernel; its backward is the shared OCN_EPI_DGELU multiply"""
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = bf(torch.randn(M, K, generator=g)).to(dev)
+    b = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux = torch.full((M, N), 255, dtype=torch.uint8, device=dev)
+    out = ops.gemm_nt(ops.EPI_BIAS_QUICKGELU, a, b, torch.empty(M, N, dtype=torch.bfloat16, device=dev), bias=bias, aux=aux)
+    pre = (a.float() @ b.float().t() + bias).requires_grad_(True)
+    act = pre * torch.sigmoid(1.702 * pre)
+    act.backward(torch.ones_like(act))
+    tag = f"gemm_nt[{M}x{N}x{K}] quickgelu"
+    check(tag + ".out", out, act.detach(), bf16_out=True, abs_tol=1e-3)
+    check_saved_derivative(tag + ".saved_derivative", aux, pre.grad)
+
+
 @pytest.mark.parametrize("variant", [4, 5])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (1000, 640, 320), (2500, 768, 1024), (513, 1027, 96), (37, 6, 32), (70000, 512, 256), (66000, 264, 128)])
 def test_gemm_nt_every_kernel_variant(dev, variant, M, N, K):

@@ -18,10 +18,12 @@ def _close(a, b, tol=TOL):
     return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True)])
+@pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True), ("tiny_quickgelu.npz", False)])
 def test_tiny_forward_backward_matches_reference(name, siglip):
     g = load(name)
     cfg = get_model_config("tiny-test")
+    if "quickgelu" in name:  # reference CLIP(quick_gelu=True): QuickGELU in both towers (layers.py:29-32)
+        cfg["quick_gelu"] = True
     state = state_from_golden(g)
     image = torch.from_numpy(g["image"].astype(np.float32))
     text = torch.from_numpy(g["text"])
