@@ -172,11 +172,11 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
+        const float alpha = fast_exp2(m - mn);
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            st[r] = exp2f(st[r] - mn);
+            st[r] = fast_exp2(st[r] - mn);
             ps += st[r];
         }
         l = l * alpha + ps;
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__
 // ------------------------------------------------------------------------------------------------
 // WPE = waves per SIMD the register allocation is held to (2: up to 256 VGPRs; 3: 168 -- a handful of spills, but a third
 // 3-wave workgroup fits on a CU at the text tower's L = 77, where LDS would allow three and 236 VGPRs allow two)
-template <int MAXT, int WPE>
+// TWO_PASS: dV and dK in two sub-passes over the query blocks (S is recomputed in the second: +4 of 16 MFMAs per block) so that only ONE
+// pair of 32 x 64 accumulators is live at a time and each result leaves through the wave's own rows of the V image as soon as it is
+// complete -- the live set fits 168 registers (three waves per SIMD, six workgroups of two waves per CU instead of four) without spills.
+template <int MAXT, int WPE, bool TWO_PASS = false>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, int causal,
@@ -294,7 +297,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + mfma32_row(r, lane);
                 const bool ok = key < L && query < L && (!causal || key <= query);
-                const float p = ok ? exp2f(st[r] * sc - lse_q) : 0.f;
+                const float e = fast_exp2(st[r] * sc - lse_q);
+                    const float p = ok ? e : 0.f;
                 st[r] = p * (dp[r] - delta_q) * scale;
             }
 #pragma unroll
@@ -325,8 +329,63 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         if (!(ablate & 4)) flush_tile(sB, wave * 32, lane, dbase, rs, L);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
         const int qb0 = ((ablate & 2) || !active) ? nb : (causal ? kb : 0);
+        if constexpr (TWO_PASS) {
+            // the wave's rows of the V image carried dQ out; their reads are complete (flush_tile), so dV and then dK leave the same way,
+            // with no barrier: nobody else touches these rows, and the Q / dO images stay intact for the other waves
+            {
+                f32x16 dv0 = zero16(), dv1 = zero16();
+                for (int qb = qb0; qb < nb; ++qb) {
+                    f32x16 st = zero16();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) st = mfma32(frag_rows(sA, qb * 32 + lr, s, lane), kf[s], st);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int query = qb * 32 + mfma32_row(r, lane);
+                        const bool ok = key < L && query < L && (!causal || key <= query);
+                        const float e = fast_exp2(st[r] * sc - sLse[query]);
+                        st[r] = ok ? e : 0.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 pf = pack8(st, t);
+                        dv0 = mfma32(frag_cols(sC, qb * 32, t, 0, lane), pf, dv0);
+                        dv1 = mfma32(frag_cols(sC, qb * 32, t, 1, lane), pf, dv1);
+                    }
+                }
+                stage_tile(sB, wave * 32, lane, dv0, dv1, 1.0f);
+                if (!(ablate & 4)) flush_tile(sB, wave * 32, lane, dbase + 2 * C, rs, L);
+            }
+            {
+                f32x16 dk0 = zero16(), dk1 = zero16();
+                for (int qb = qb0; qb < nb; ++qb) {
+                    f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        st = mfma32(frag_rows(sA, qb * 32 + lr, s, lane), kf[s], st);
+                        dp = mfma32(frag_rows(sC, qb * 32 + lr, s, lane), vf[s], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int query = qb * 32 + mfma32_row(r, lane);
+                        const bool ok = key < L && query < L && (!causal || key <= query);
+                        const float ls = sLse[query], dl = sDelta[query];
+                        const float e = fast_exp2(st[r] * sc - ls);
+                        const float p = ok ? e : 0.f;
+                        dp[r] = p * (dp[r] - dl) * scale;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 dsf = pack8(dp, t);
+                        dk0 = mfma32(frag_cols(sA, qb * 32, t, 0, lane), dsf, dk0);
+                        dk1 = mfma32(frag_cols(sA, qb * 32, t, 1, lane), dsf, dk1);
+                    }
+                }
+                stage_tile(sB, wave * 32, lane, dk0, dk1, 1.0f);
+                if (!(ablate & 4)) flush_tile(sB, wave * 32, lane, dbase + C, rs, L);
+            }
+        } else {
+        f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
         for (int qb = qb0; qb < nb; ++qb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
@@ -338,8 +397,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             for (int r = 0; r < 16; ++r) {
                 const int query = qb * 32 + mfma32_row(r, lane);
                 const bool ok = key < L && query < L && (!causal || key <= query);
-                const float p = ok ? exp2f(st[r] * sc - sLse[query]) : 0.f;
-                dp[r] = p * (dp[r] - sDelta[query]) * scale;
+                const float ls = sLse[query], dl = sDelta[query];  // read unconditionally: under `ok ? ... : 0` hipcc branches around every element
+                const float e = fast_exp2(st[r] * sc - ls);
+                const float p = ok ? e : 0.f;
+                dp[r] = p * (dp[r] - dl) * scale;
                 st[r] = p;
             }
 #pragma unroll
@@ -358,6 +419,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         if (!(ablate & 4)) {
             flush_tile(sA, wave * 32, lane, dbase + C, rs, L);
             flush_tile(sC, wave * 32, lane, dbase + 2 * C, rs, L);
+        }
         }
     }
 }
@@ -443,7 +505,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * 32 + mfma32_row(r, lane);
                 const bool ok = key < L && query < L && key <= query;
-                const float p = ok ? exp2f(st[r] * sc - lse_q) : 0.f;
+                const float e = fast_exp2(st[r] * sc - lse_q);
+                    const float p = ok ? e : 0.f;
                 st[r] = p * (dp[r] - delta_q) * scale;
             }
 #pragma unroll
@@ -479,8 +542,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
             for (int r = 0; r < 16; ++r) {
                 const int qq = q2 * 32 + mfma32_row(r, lane);
                 const bool ok = key < L && qq < L && key <= qq;
-                const float p = ok ? exp2f(st[r] * sc - sLse[qq]) : 0.f;
-                dp[r] = p * (dp[r] - sDelta[qq]) * scale;
+                const float ls = sLse[qq], dl = sDelta[qq];
+                const float e = fast_exp2(st[r] * sc - ls);
+                const float p = ok ? e : 0.f;
+                dp[r] = p * (dp[r] - dl) * scale;
                 st[r] = p;
             }
 #pragma unroll
@@ -499,6 +564,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
         flush_tile(sT, wave * 32, lane, dbase + 2 * C, rs, L);
     }
 }
+
+#ifndef OCN_ATTN_BWD_TWO_PASS_DEFAULT
+#define OCN_ATTN_BWD_TWO_PASS_DEFAULT true  // up to 128 tokens (profiles/r03_attention_backward_two_pass.txt: -4 % at 50 tokens; slower at 257)
+#endif
 
 int check_attn(const char* name, int B, int L, int H) {
     OCN_CHECK_ARG(B > 0 && H > 0 && L > 0, "%s: bad shape B=%d L=%d H=%d", name, B, L, H);
@@ -570,14 +639,16 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
         OCN_CHECK_LAUNCH("ocn_attn_bwd");
         return OCN_OK;
     }
-    const bool three = g_ocn_tuning[2] == 3;  // developer knob 2 = 3: the 168-VGPR build (3 waves per SIMD, ~22 spilled registers; measured no faster: profiles/r01_attn_bwd_two_pass.txt)
-    if (nw <= 4 && three) {
+    // two-pass dK / dV build (168 registers, three waves per SIMD, no spills): developer knob 2 = 4 selects it, 2 = 5 forces the one-pass
+    // build; default: see OCN_ATTN_BWD_TWO_PASS_DEFAULT
+    const bool two_pass = g_ocn_tuning[2] == 4 || (g_ocn_tuning[2] != 5 && OCN_ATTN_BWD_TWO_PASS_DEFAULT && nw <= 4);
+    if (nw <= 4 && two_pass) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_bwd_kernel<256, 3>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+        hipLaunchKernelGGL((attn_bwd_kernel<256, 3, true>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
     } else if (nw <= 4) {
         static bool attr_set = false;
@@ -591,9 +662,13 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<640, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<640, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_bwd_kernel<640, 1>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+        // up to 10 waves per workgroup: three per SIMD, 168 registers -- the one-pass build spills 17 of them there, the two-pass one none
+        if (two_pass) hipLaunchKernelGGL((attn_bwd_kernel<640, 1, true>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
+        else hipLaunchKernelGGL((attn_bwd_kernel<640, 1>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
                            (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
     }
     OCN_CHECK_LAUNCH("ocn_attn_bwd");
@@ -647,9 +722,24 @@ int ocn_launch_attn_generic_fwd(const void* qkv, void* out, float* lse, int B, i
 int ocn_launch_attn_generic_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int B,
                                 int L, int H, int D, int causal, float scale, hipStream_t st);
 
+// head_dim 64: the head-resident kernels above (one workgroup per head) up to OCN_ATTN_RESIDENT_MAX_L tokens, the streamed kernels of
+// attention_generic.hip beyond (at 257 tokens a resident head is 110 KB of LDS: one workgroup per CU, loads serialised in front of the
+// arithmetic); developer knob 7: 1 = always streamed, 2 = always resident (L <= 320)
+// measured at ViT-L-14's 257 tokens (profiles/r03_attention_long_sequences.txt): forward 2.13 ms streamed vs 2.49 resident, backward 6.3 vs 5.7
+#ifndef OCN_ATTN_RESIDENT_MAX_L_FWD
+#define OCN_ATTN_RESIDENT_MAX_L_FWD 128
+#endif
+#ifndef OCN_ATTN_RESIDENT_MAX_L_BWD
+#define OCN_ATTN_RESIDENT_MAX_L_BWD 320
+#endif
+static bool attn_use_resident(int head_dim, int L, int max_l) {
+    if (head_dim != 64 || L > 320 || g_ocn_tuning[7] == 1) return false;
+    return g_ocn_tuning[7] == 2 || L <= max_l;
+}
+
 extern "C" int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, int causal, float scale,
                                ocn_stream_t stream) {
-    if (head_dim == 64 && L <= 320 && g_ocn_tuning[7] != 1) return ocn_attn_fwd(qkv, out, lse, B, L, H, causal, scale, stream);  // knob 7 = 1: force the generic path
+    if (attn_use_resident(head_dim, L, OCN_ATTN_RESIDENT_MAX_L_FWD)) return ocn_attn_fwd(qkv, out, lse, B, L, H, causal, scale, stream);
     OCN_CHECK_ARG(qkv && out && lse && B > 0 && L > 0 && H > 0, "ocn_attn_fwd_hd: bad arguments");
     const int rc = ocn_launch_attn_generic_fwd(qkv, out, lse, B, L, H, head_dim, causal, scale, (hipStream_t)stream);
     if (rc == 1) {
@@ -662,7 +752,7 @@ extern "C" int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, in
 
 extern "C" int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B,
                                int L, int H, int head_dim, int causal, float scale, ocn_stream_t stream) {
-    if (head_dim == 64 && L <= 320 && g_ocn_tuning[7] != 1) return ocn_attn_bwd(qkv, out, dout, lse, dqkv, B, L, H, causal, scale, stream);
+    if (attn_use_resident(head_dim, L, OCN_ATTN_RESIDENT_MAX_L_BWD)) return ocn_attn_bwd(qkv, out, dout, lse, dqkv, B, L, H, causal, scale, stream);
     OCN_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "ocn_attn_bwd_hd: bad arguments");
     const int rc = ocn_launch_attn_generic_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, L, H, head_dim, causal, scale, (hipStream_t)stream);
     if (rc == 1) {

@@ -41,6 +41,10 @@ void ocn_set_error(const char* fmt, ...);
 OCN_DEV float bf2f(bf16 v) { return (float)v; }
 OCN_DEV bf16 f2bf(float v) { return (bf16)v; }  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
 
+// 2^x by the hardware instruction alone (v_exp_f32, 1 ulp): the softmax kernels work in the exp2 domain and only ever see x <= 0 or a
+// discarded lane -- exp2f() adds a denormal-range rescue (5 more VALU operations per element) that nothing here needs
+OCN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 OCN_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
