@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--serial-towers", action="store_true", help="image and text tower on ONE stream (default: the image tower on a stream of its own next "
-                    "to the text tower, model.py::_TOWER_SIDE; the steps whose GEMM launches carry HIP events always run serially)")
+                    "to the text tower, NativeCLIP._tower_side; the steps whose GEMM launches carry HIP events always run serially)")
     ap.add_argument("--no-wgrad-pair", action="store_true", help="with --serial-towers: no wgrad side stream either (every kernel alone on the chip: the "
                     "configuration of the event-timed steps, used for the rocprofv3 / PMC passes)")
     ap.add_argument("--no-dense-text-line", action="store_true", help="skip the extra --dense-text timing that the default line carries")

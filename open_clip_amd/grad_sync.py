@@ -134,9 +134,8 @@ class NativeGradSync:
             for flat, _ in ranges:
                 self._allreduce_mean(flat)
             return
-        from .model import _TOWER_SIDE
         cs.wait_stream(torch.cuda.current_stream(dev))      # the stream the hook (and the producing backward) runs on
-        side = _TOWER_SIDE.get(dev)
+        side = getattr(self.model, "_tower_side", {}).get(dev)
         if side is not None:
             cs.wait_stream(side)                            # the image tower's backward, when the towers run on two streams
         with torch.cuda.stream(cs):

@@ -36,6 +36,16 @@ class _WeightCache:
         self._d = {}
         self.pair_wgrad = True  # block backward: run the wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.deterministic = False  # weight / bias gradient GEMMs in their reproducible form (ocn_gemm_tn_accum_det)
+        self._side = {}  # wgrad side streams of this tower, one per (device, main stream)
+        self.twin_stats = {"hit": 0, "miss": 0}  # how often a block's backward found the bf16 twin of its incoming gradient (tests assert it does)
+
+    def side_stream(self, dev):
+        """the wgrad stream that belongs to the CURRENT stream (one per main stream: the towers may run on streams of their own)"""
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        st = self._side.get(key)
+        if st is None:
+            st = self._side[key] = torch.cuda.Stream(device=dev)
+        return st
 
     def get(self, p: torch.Tensor, kind: str):
         """kind: 'n' = bf16 copy [rows, cols]; 't' = bf16 transpose [cols, rows] (2-D views of p)"""
@@ -81,20 +91,17 @@ class _WeightCache:
 # tensor (autograd summed two branches, a hook replaced the gradient, ...) finds no attribute and casts.
 # ------------------------------------------------------------------------------------------------------
 # ------------------------------------------------------------------------------------------------------
-TWIN_STATS = {"hit": 0, "miss": 0}  # how often the hand-off was taken (tests assert it is)
-
 
 def _publish_twin(g32, g16):
     g32._ocn_bf16_twin = (g16, g32._version)
 
 
-def _take_twin(g32):
+def _take_twin(g32, cache=None):
     tw = getattr(g32, "_ocn_bf16_twin", None)
-    if tw is not None and tw[1] == g32._version and tw[0].shape == g32.shape and tw[0].device == g32.device:
-        TWIN_STATS["hit"] += 1
-        return tw[0]
-    TWIN_STATS["miss"] += 1
-    return ops.cast_bf16(g32)
+    hit = tw is not None and tw[1] == g32._version and tw[0].shape == g32.shape and tw[0].device == g32.device
+    if cache is not None:
+        cache.twin_stats["hit" if hit else "miss"] += 1
+    return tw[0] if hit else ops.cast_bf16(g32)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -110,18 +117,6 @@ def _take_twin(g32):
 # workgroups start late ends late), and the block's gradients are complete on the main stream when they are handed to
 # autograd (DDP hooks / the optimizer run there).  ``model.pair_wgrad = False`` keeps everything on one stream.
 # ------------------------------------------------------------------------------------------------------
-_SIDE = {}
-
-
-def _side_stream(dev):
-    """the wgrad stream that belongs to the CURRENT stream (one per main stream: the towers may run on streams of their own)"""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    st = _SIDE.get(key)
-    if st is None:
-        st = _SIDE[key] = torch.cuda.Stream(device=dev)
-    return st
-
-
 # The two towers are independent until the loss.  With ``tower_streams`` the IMAGE tower runs on a stream of its own (forward and,
 # through autograd's per-node stream bookkeeping, backward) next to the text tower on the caller's stream: the tail of one tower's
 # persistent GEMM (a last round that fills 37-43 % of the CUs at N = 768 / 512) and its HBM-bound kernels are filled by the other
@@ -129,8 +124,7 @@ def _side_stream(dev):
 # accumulates every parameter gradient on the stream the accumulator was created on -- under DDP the caller's stream -- behind a
 # wait for the producing node: text-tower nodes (created last, run first in backward) sit on the caller's stream and wait for nothing,
 # the waits for the image tower's blocks queue up behind them.  The per-block wgrad side streams (_Paired) are switched off in this
-# mode (two MFMA-bound streams are enough; measured 191.5 with, 188.1 without).
-_TOWER_SIDE = {}
+# mode (two MFMA-bound streams are enough; measured 191.5 with, 188.1 without).  The stream belongs to the model (``NativeCLIP._tower_side``).
 
 
 class _AfterStream(torch.autograd.Function):
@@ -152,11 +146,11 @@ class _AfterStream(torch.autograd.Function):
 
 
 class _Paired:
-    """``with _Paired(dev) as side: side(fn, ...)`` enqueues fn on the side stream after everything already on the main
+    """``with _Paired(dev, cache) as side: side(fn, ...)`` enqueues fn on the side stream after everything already on the main
     stream; leaving the block joins the side stream back into the main stream."""
 
-    def __init__(self, dev, enabled=True):
-        self.side = _side_stream(dev) if enabled else None
+    def __init__(self, dev, cache, enabled=True):
+        self.side = cache.side_stream(dev) if enabled else None
         self.main = torch.cuda.current_stream(dev) if self.side is not None else None
 
     def __enter__(self):
@@ -232,7 +226,7 @@ class _BlockFn(torch.autograd.Function):
         (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g) = saved
         M, C = x.shape
         Fd = wfc.shape[0]
-        dy16 = _take_twin(dy)
+        dy16 = _take_twin(dy, cache)
         dy = dy.contiguous()
         # one zeroed fp32 arena for all of the block's parameter gradients (wgrad kernels accumulate atomically)
         grads = _grad_arena(p)
@@ -247,18 +241,18 @@ class _BlockFn(torch.autograd.Function):
         df = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((M, Fd), BF16, x), aux=f)
         dh2 = ops.gemm_nt(ops.EPI_BF16, df, cache.get(wfc, "t"), ops.empty((M, C), BF16, x))
         pair, det = cache.pair_wgrad, cache.deterministic
-        with _Paired(dev, pair) as side:
+        with _Paired(dev, cache, pair) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj, 1.0, det)
             dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, pair) as side:
+        with _Paired(dev, cache, pair) as side:
             if need_w:
                 side(ops.gemm_tn_accum, df, h2, dwfc, dbfc, 1.0, det)
             dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
-        with _Paired(dev, pair) as side:
+        with _Paired(dev, cache, pair) as side:
             if need_w and det:
                 side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo, 1.0, True)
                 side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv, 1.0, True)
@@ -322,7 +316,7 @@ class _PooledBlockFn(torch.autograd.Function):
         (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p) = saved
         M, C = x.shape
         Fd = wfc.shape[0]
-        dy16 = _take_twin(dy_p)
+        dy16 = _take_twin(dy_p, cache)
         dy_p = dy_p.contiguous()
         grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
@@ -797,7 +791,8 @@ class NativeCLIP(nn.Module):
         # ``pack_text = False`` runs every one of the context_length positions like the reference does
         self.pack_text = bool(pack_text) and t["width"] // t["heads"] == 64 and self.context_length <= 320
         self.attn_buckets = bool(attn_buckets)
-        # True: image tower on a stream of its own next to the text tower (see _TOWER_SIDE); False: one stream; "serial": the same two
+        self._tower_side = {}  # device -> the image tower's stream (created on first use)
+        # True: image tower on a stream of its own next to the text tower (see _AfterStream / forward); False: one stream; "serial": the same two
         # streams, one tower at a time (bench.py's event-timed steps)
         self.tower_streams = tower_streams
         # the last block of each tower only where its output is read (see _PooledBlockFn); the image tower has its own switch
@@ -912,9 +907,9 @@ class NativeCLIP(nn.Module):
         if overlap:
             dev = text.device
             cur = torch.cuda.current_stream(dev)
-            side = _TOWER_SIDE.get(dev)
+            side = self._tower_side.get(dev)
             if side is None:
-                side = _TOWER_SIDE[dev] = torch.cuda.Stream(device=dev)
+                side = self._tower_side[dev] = torch.cuda.Stream(device=dev)
             serial = self.tower_streams == "serial"  # one tower at a time, on the same two streams (see _AfterStream)
             side.wait_stream(cur)
             with torch.cuda.stream(side):

@@ -236,12 +236,13 @@ def test_state_carried_between_steps_is_not_stale():
     m1.zero_grad(set_to_none=True)
     _, l1 = _step(m1, b)
     m2 = _build(cfg, state)
-    import open_clip_amd.model as M
-    M.TWIN_STATS.update(hit=0, miss=0)
+    stats = [m2._cache.twin_stats, m2.visual._cache.twin_stats]
+    for st in stats:
+        st.update(hit=0, miss=0)
     _, l2 = _step(m2, b)
     # the bf16 twin of the residual-stream gradient rides on the gradient tensor from block to block: every block backward of both
     # towers (2 + 2 here) must have found it (a miss is only a cast kernel, but then the optimisation would be silently gone)
-    assert M.TWIN_STATS["hit"] >= 4 and M.TWIN_STATS["miss"] == 0, M.TWIN_STATS
+    assert sum(st["hit"] for st in stats) >= 4 and sum(st["miss"] for st in stats) == 0, stats
     assert abs(float(l1.detach()) - float(l2.detach())) < 1e-6
     for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         rel = float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-30))
