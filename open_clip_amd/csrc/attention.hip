@@ -120,8 +120,10 @@ OCN_DEV void flush_tile(const char* img, int row0, int lane, bf16* base, size_t 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// (three waves per SIMD asked for: with the whole 512-register file on offer hipcc keeps the MFMA accumulators in AGPRs and moves every one of
+// them to a VGPR and back around the softmax arithmetic -- 144 v_accvgpr moves in this kernel)
 template <int MAXT, bool NTL>
-__global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3))) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                          float* __restrict__ lse, const int32_t* __restrict__ seq_off, int Lmax, int H,
                                                          int causal, float scale, const int32_t* __restrict__ order, int order_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

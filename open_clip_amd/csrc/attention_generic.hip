@@ -17,7 +17,7 @@
 //   * D = 80 needs no padding of the contraction (5 MFMA k-steps of 16); as an OUTPUT dimension it is covered by three 32-wide blocks
 //     whose last 16 columns multiply whatever follows the row in LDS and are never stored;
 //   * workgroups of one head are adjacent in the grid (they share K / V resp. Q / dO through the Infinity Cache);
-//   * the backward is two launches (dQ, then dK / dV) that exchange delta[q] = sum_d dO O through a caller-provided fp32 workspace.
+//   * the backward is three launches (dQ, dV, dK) that exchange delta[q] = sum_d dO O through a caller-provided fp32 workspace.
 #include "ocn_common.h"
 
 namespace {
@@ -151,7 +151,7 @@ OCN_DEV void store_rows(bf16* __restrict__ base, size_t rs, int row, int rows, i
 // forward: grid = B*H heads x groups of 4 query blocks (groups fastest), 256 threads
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_s_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+__global__ __launch_bounds__(256, 2) void attn_s_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
                                                          int L, int H, int BH, int groups, int causal, float scale) {
     using G = Geo<D>;
     constexpr int DB = G::DB, KS = G::KS, P = G::PITCH;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_s_fwd_kernel(const bf16* __restrict_
 // backward, kernel 1: dQ for 4 query blocks (K, V streamed); writes delta[q]
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_s_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_s_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                             bf16* __restrict__ dqkv, float* __restrict__ delta, int L, int H, int BH, int groups,
                                                             int causal, float scale) {
@@ -377,14 +377,19 @@ __global__ __launch_bounds__(256) void attn_s_bwd_dq_kernel(const bf16* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, kernel 2: dK, dV for 4 key blocks (Q, dO and their LSE / delta streamed; delta written by kernel 1)
+// backward, kernels 2 and 3: dV (WHAT = 1) resp. dK (WHAT = 2) for 4 key blocks (Q, dO and their LSE / delta streamed; delta written by
+// kernel 1).  One launch each: with both accumulator sets (2 x DB x 16 registers) next to the K and V fragments and the staging registers
+// a wave needs the whole 256-register budget (one 4-wave workgroup per CU; spills at head_dim 96 / 128) -- apart, the dV kernel fits three
+// workgroups per CU and the dK kernel two.  The price: S = K Q^T is evaluated in both (5 of 27 MFMAs per block pair at head_dim 80) and
+// Q / dO are streamed twice (mostly out of the L2 / Infinity Cache: the workgroups of a head run together on one XCD).
 // ------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void attn_s_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             bf16* __restrict__ dqkv, int L, int H, int BH, int groups, int causal, float scale) {
+template <int D, int WHAT>
+__global__ __launch_bounds__(256, 2) void attn_s_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16* __restrict__ dqkv, int L, int H, int BH, int groups, int causal, float scale) {
     using G = Geo<D>;
     constexpr int DB = G::DB, KS = G::KS, P = G::PITCH;
+    constexpr bool DV = WHAT == 1;
     constexpr int SLOT = 2 * G::BUF + 2 * CH * 4;  // Q | dO | lse[64] | delta[64]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -403,11 +408,11 @@ __global__ __launch_bounds__(256) void attn_s_bwd_dkv_kernel(const bf16* __restr
     const int lr = lane & 31;
     const int key = kb * 32 + lr;
     const int krow = key < L ? key : L - 1;
-    bf16x8 kf[KS], vf[KS];
+    bf16x8 kf[KS], vf[DV ? 1 : KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         kf[s] = frag_rows_g(qbase + C, rs, krow, s, lane);
-        vf[s] = frag_rows_g(qbase + 2 * C, rs, krow, s, lane);
+        if constexpr (!DV) vf[s] = frag_rows_g(qbase + 2 * C, rs, krow, s, lane);
     }
     // query chunks this workgroup walks: causal -> from its first key block on
     const int c0 = causal ? (grp * 4) / 2 : 0;
@@ -432,16 +437,13 @@ __global__ __launch_bounds__(256) void attn_s_bwd_dkv_kernel(const bf16* __restr
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         settle(kf[s]);
-        settle(vf[s]);
+        if constexpr (!DV) settle(vf[s]);
     }
 
     const float sc = scale * LOG2E;
-    f32x16 dk[DB], dv[DB];
+    f32x16 acc[DB];  // dV or dK
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-        dk[db] = zero16();
-        dv[db] = zero16();
-    }
+    for (int db = 0; db < DB; ++db) acc[db] = zero16();
     for (int c = c0; c < nch; ++c) {
         const char* slot = smem + ((c - c0) & 1) * SLOT;
         const char* sQ = slot;
@@ -460,11 +462,11 @@ __global__ __launch_bounds__(256) void attn_s_bwd_dkv_kernel(const bf16* __restr
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     st = mfma32(frag_rows_p<P>(sQ, qbi * 32 + lr, s, lane), kf[s], st);
-                    dp = mfma32(frag_rows_p<P>(sdO, qbi * 32 + lr, s, lane), vf[s], dp);
+                    if constexpr (!DV) dp = mfma32(frag_rows_p<P>(sdO, qbi * 32 + lr, s, lane), vf[s], dp);
                 }
                 // masks only where they can bite: the last query block (queries >= L are copies of the last row) and the causal diagonal; rows
                 // of keys >= L are dropped by the store.  The statistics are read unconditionally (under `ok ? ... : 0` hipcc branches around
-                // every element).
+                // every element).  st <- P (dV) or dS = P (dP - delta) scale (dK)
                 const bool edge = (qb == nblk - 1 && (L & 31) != 0) || (causal && qb == kb);
                 if (edge) {
 #pragma unroll
@@ -472,29 +474,23 @@ __global__ __launch_bounds__(256) void attn_s_bwd_dkv_kernel(const bf16* __restr
                         const int ql = qbi * 32 + mfma32_row(r, lane);  // query inside the chunk
                         const int query = c * CH + ql;
                         const bool ok = query < L && (!causal || key <= query);
-                        const float ls = sLse[ql], dl = sDelta[ql];
-                        const float e = fast_exp2(st[r] * sc - ls);
+                        const float e = fast_exp2(st[r] * sc - sLse[ql]);
                         const float p = ok ? e : 0.f;
-                        dp[r] = p * (dp[r] - dl) * scale;
-                        st[r] = p;
+                        st[r] = DV ? p : p * (dp[r] - sDelta[ql]) * scale;
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ql = qbi * 32 + mfma32_row(r, lane);
                         const float p = fast_exp2(st[r] * sc - sLse[ql]);
-                        dp[r] = p * (dp[r] - sDelta[ql]) * scale;
-                        st[r] = p;
+                        st[r] = DV ? p : p * (dp[r] - sDelta[ql]) * scale;
                     }
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const bf16x8 pf = pack8(st, t), dsf = pack8(dp, t);
+                    const bf16x8 f = pack8(st, t);
 #pragma unroll
-                    for (int db = 0; db < DB; ++db) {
-                        dv[db] = mfma32(frag_cols_p<P>(sdO, qbi * 32, t, db, lane), pf, dv[db]);
-                        dk[db] = mfma32(frag_cols_p<P>(sQ, qbi * 32, t, db, lane), dsf, dk[db]);
-                    }
+                    for (int db = 0; db < DB; ++db) acc[db] = mfma32(frag_cols_p<P>(DV ? sdO : sQ, qbi * 32, t, db, lane), f, acc[db]);
                 }
             }
         }
@@ -508,8 +504,7 @@ __global__ __launch_bounds__(256) void attn_s_bwd_dkv_kernel(const bf16* __restr
     }
     if (kb >= nblk) return;
     bf16* dbase = dqkv + (size_t)b * L * rs + hd * D;
-    store_rows<D, DB>(dbase + C, rs, key, L, lane, dk, 1.0f);
-    store_rows<D, DB>(dbase + 2 * C, rs, key, L, lane, dv, 1.0f);
+    store_rows<D, DB>(dbase + (DV ? 2 * C : C), rs, key, L, lane, acc, 1.0f);
 }
 
 template <int D>
@@ -535,7 +530,8 @@ int launch_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* 
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_s_bwd_dq_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_s_bwd_dkv_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_s_bwd_dkv_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_s_bwd_dkv_kernel<D, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int groups = ocn_cdiv(ocn_cdiv(L, 32), 4);
@@ -543,7 +539,9 @@ int launch_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* 
     if (grid > 0x7fffffffL) return 1;
     hipLaunchKernelGGL(attn_s_bwd_dq_kernel<D>, dim3((unsigned)grid), dim3(256), 4 * G::BUF + 64, st, qkv, out, dout, lse, dqkv, delta, L, H, B * H, groups,
                        causal, scale);
-    hipLaunchKernelGGL(attn_s_bwd_dkv_kernel<D>, dim3((unsigned)grid), dim3(256), 2 * (2 * G::BUF + 2 * CH * 4) + 64, st, qkv, dout, lse, delta, dqkv, L,
+    hipLaunchKernelGGL((attn_s_bwd_dkv_kernel<D, 1>), dim3((unsigned)grid), dim3(256), 2 * (2 * G::BUF + 2 * CH * 4) + 64, st, qkv, dout, lse, delta, dqkv, L,
+                       H, B * H, groups, causal, scale);
+    hipLaunchKernelGGL((attn_s_bwd_dkv_kernel<D, 2>), dim3((unsigned)grid), dim3(256), 2 * (2 * G::BUF + 2 * CH * 4) + 64, st, qkv, dout, lse, delta, dqkv, L,
                        H, B * H, groups, causal, scale);
     return 0;
 }

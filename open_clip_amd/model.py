@@ -36,7 +36,7 @@ class _WeightCache:
         self._d = {}
         self.pair_wgrad = True  # block backward: run the wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.deterministic = False  # weight / bias gradient GEMMs in their reproducible form (ocn_gemm_tn_accum_det)
-        self._side = {}  # wgrad side streams of this tower, one per (device, main stream)
+        self._side = _StreamMap()  # wgrad side streams of this tower, one per (device, main stream)
         self.twin_stats = {"hit": 0, "miss": 0}  # how often a block's backward found the bf16 twin of its incoming gradient (tests assert it does)
 
     def side_stream(self, dev):
@@ -125,6 +125,14 @@ def _take_twin(g32, cache=None):
 # wait for the producing node: text-tower nodes (created last, run first in backward) sit on the caller's stream and wait for nothing,
 # the waits for the image tower's blocks queue up behind them.  The per-block wgrad side streams (_Paired) are switched off in this
 # mode (two MFMA-bound streams are enough; measured 191.5 with, 188.1 without).  The stream belongs to the model (``NativeCLIP._tower_side``).
+
+
+class _StreamMap(dict):
+    """device / (device, stream) -> torch.cuda.Stream, owned by a model or a tower cache; a deep copy of the owner (the EMA twin of
+    base_task.py:171) starts with an empty map instead of trying to copy stream handles"""
+
+    def __deepcopy__(self, memo):
+        return _StreamMap()
 
 
 class _AfterStream(torch.autograd.Function):
@@ -791,7 +799,7 @@ class NativeCLIP(nn.Module):
         # ``pack_text = False`` runs every one of the context_length positions like the reference does
         self.pack_text = bool(pack_text) and t["width"] // t["heads"] == 64 and self.context_length <= 320
         self.attn_buckets = bool(attn_buckets)
-        self._tower_side = {}  # device -> the image tower's stream (created on first use)
+        self._tower_side = _StreamMap()  # device -> the image tower's stream (created on first use)
         # True: image tower on a stream of its own next to the text tower (see _AfterStream / forward); False: one stream; "serial": the same two
         # streams, one tower at a time (bench.py's event-timed steps)
         self.tower_streams = tower_streams
