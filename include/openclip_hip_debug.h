@@ -22,12 +22,12 @@ extern "C" {
 int ocn_set_gemm_variant(int nt_variant);
 /* developer knobs (process-global; experiments and A/B measurements of tools/sweep.py, never needed by a user):
  *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)
- *   key 2  attention backward: 3 = the 168-VGPR build (3 waves per SIMD)      key 4  wgrad GEMM: 1 = skip the atomic epilogue
+ *   key 2  attention backward: 4 = two-pass dK / dV build, 5 = one-pass build (default: two-pass up to 4 waves)   key 4  wgrad GEMM: 1 = skip the atomic epilogue
  *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
- *   key 7  1 = force the generic (explicit head_dim) attention kernels          key 8  1 = LayerNorm backward, default cache policy
+ *   key 7  1 = always the streamed (explicit head_dim) attention kernels, 2 = always the head-resident ones (head_dim 64, L <= 320)
+ *   key 8  1 = LayerNorm backward, default cache policy
  *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
  *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
- *   key 12 2 = wgrad GEMM may use the workspace (partial tiles + reduce) epilogue (off by default: no gain on the step)
  *   key 13 1 = ocn_gemm_tn_accum2 never pairs (runs its two problems as two launches: A/B of the paired wgrad)
  *   key 14 n = workgroups of the LayerNorm backward's grid (default: one 16-wave workgroup per CU) */
 int ocn_set_tuning(int key, int value);

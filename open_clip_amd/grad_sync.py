@@ -108,10 +108,13 @@ class NativeGradSync:
         import torch.distributed as dist
         with torch.no_grad():
             for t in list(self.model.parameters()) + list(self.model.buffers()):
-                if self.comm is not None:
+                if self.comm is not None:  # the C ABI has no broadcast: zero everywhere but on rank 0, then sum (fp32 / bf16 tensors)
+                    buf = t.data if t.is_contiguous() else t.data.contiguous()
                     if self.comm.rank != 0:
-                        t.zero_()
-                    self.comm.all_reduce_sum(t.data if t.is_contiguous() else t.data.contiguous())
+                        buf.zero_()
+                    self.comm.all_reduce_sum(buf)
+                    if buf is not t.data and buf.data_ptr() != t.data.data_ptr():
+                        t.data.copy_(buf)
                 else:
                     dist.broadcast(t.data, src=0, group=self.pg)
         if hasattr(self.model, "invalidate_weight_caches"):
