@@ -28,6 +28,7 @@ int ocn_set_gemm_variant(int nt_variant);
  *   key 8  1 = LayerNorm backward, default cache policy
  *   key 9  2 = attention forward, non-temporal policy for its LDS-DMA loads
  *   key 10 workgroups per CU of the persistent NT GEMM's grid (0 = default 1)   key 11 wgrad GEMM: M-splits per CU when few (0/1 = one)
+ *   key 12 1 = LayerNorm forward, default cache policy for x (default: non-temporal)
  *   key 13 1 = ocn_gemm_tn_accum2 never pairs (runs its two problems as two launches: A/B of the paired wgrad)
  *   key 14 n = workgroups of the LayerNorm backward's grid (default: one 16-wave workgroup per CU) */
 int ocn_set_tuning(int key, int value);

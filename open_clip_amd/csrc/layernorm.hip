@@ -11,7 +11,10 @@
 extern int g_ocn_tuning[16];
 namespace {
 
-template <int NV>
+// NTX: x (read again only by the backward, a whole forward later) is loaded with the non-temporal policy: 100 -> 89 us on the packed
+// text rows, nothing on the image rows (profiles/r03_layernorm_forward_variants.txt; fetching gamma / beta once per wave before the row
+// loop instead of per row was 3-10 % slower there and is gone).
+template <int NV, bool NTX>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ b, bf16* __restrict__ y16,
                                                       float* __restrict__ y32, float* __restrict__ mean,
@@ -25,7 +28,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
-            if (c < C) v[i] = *(const f32x4*)(xr + c); else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < C) v[i] = NTX ? __builtin_nontemporal_load((const f32x4*)(xr + c)) : *(const f32x4*)(xr + c);
+            else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
         const float mu = wave_sum(s) * invC;
@@ -207,7 +211,11 @@ int ln_bwd_grid(int M) {
 template <int NV>
 void launch_fwd(hipStream_t st, const float* x, const float* w, const float* b, bf16* y16, float* y32, float* mean, float* rstd,
                 int M, int C, float eps) {
-    ln_fwd_kernel<NV><<<dim3(ln_grid(M)), dim3(256), 0, st>>>(x, w, b, y16, y32, mean, rstd, M, C, eps);
+    const dim3 g(ln_grid(M)), t(256);
+    if (g_ocn_tuning[12] == 1)  // developer knob 12 = 1: default cache policy for x
+        ln_fwd_kernel<NV, false><<<g, t, 0, st>>>(x, w, b, y16, y32, mean, rstd, M, C, eps);
+    else
+        ln_fwd_kernel<NV, true><<<g, t, 0, st>>>(x, w, b, y16, y32, mean, rstd, M, C, eps);
 }
 template <int NV>
 void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
