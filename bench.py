@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--lr-warmup-steps", type=int, default=10000, help="linear warm-up as the reference schedules it (params.py:288, scheduler.py:6-15)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--grad-checkpointing", action="store_true")
+    ap.add_argument("--keep-blocks", default="auto",
+                    help="with --grad-checkpointing: blocks per tower whose activations are kept instead of recomputed -- 'auto' (as many as the "
+                         "free HBM holds, NativeCLIP.plan_grad_checkpointing), 'V,T' (image, text), '0' (recompute every block as the reference)")
     ap.add_argument("--serial-towers", action="store_true", help="image and text tower on ONE stream (default: the image tower on a stream of its own next "
                     "to the text tower, NativeCLIP._tower_side; the steps whose GEMM launches carry HIP events always run serially)")
     ap.add_argument("--no-wgrad-pair", action="store_true", help="with --serial-towers: no wgrad side stream either (every kernel alone on the chip: the "
@@ -293,8 +296,6 @@ def main():
     overlap_towers = model.tower_streams
     model.pair_wgrad = not args.no_wgrad_pair
     model.deterministic = args.deterministic
-    if args.grad_checkpointing:
-        model.set_grad_checkpointing(True)
     B = args.local_batch
     F_ACC = max(1, args.accum_freq)
     if args.data_ranks > 1:
@@ -307,6 +308,22 @@ def main():
     batch = micro[0]
     model_ref = model
     ctx_len = cfg["text_cfg"]["context_length"]
+    kept_blocks, recompute_share = (0, 0), 0.0
+    if args.grad_checkpointing:
+        rows_t = max(int((m["text"].argmax(dim=-1) + 1).sum()) for m in micro) if model.pack_text else None
+        if args.keep_blocks == "auto":
+            # what is not there yet when this runs: gradients, the optimizer's two moments, the bf16 operand copies (16 B / parameter);
+            # 15 % of the rest stays free for the allocator's fragmentation, the loss and the input batches
+            free = torch.cuda.mem_get_info(dev)[0] - 16 * sum(p.numel() for p in model.parameters())
+            kept_blocks = model.plan_grad_checkpointing(B, int(0.85 * free), text_rows=rows_t)
+        else:
+            kb = [int(v) for v in args.keep_blocks.split(",")]
+            kept_blocks = (kb[0], kb[-1])
+            model.set_grad_checkpointing(True, keep_last=kept_blocks)
+        bv, bt = model.activation_bytes_per_block(B, rows_t)  # bytes ~ rows x width: the towers' FLOPs split (rows x width^2) follows from them
+        nv, nt = len(model.visual.transformer.resblocks), len(model.transformer.resblocks)
+        fv, ft = bv * model.visual.transformer.width, bt * model.transformer.width
+        recompute_share = ((nv - min(nv, kept_blocks[0])) * fv + (nt - min(nt, kept_blocks[1])) * ft) / (nv * fv + nt * ft)
     if model.pack_text:
         kept = sum(int((m["text"].argmax(dim=-1) + 1).sum()) for m in micro)
         text_rows_note = (f"packed: only the tokens up to the pooled EOT exist in the text tower ({kept // len(micro)} of {B * ctx_len} rows per batch, mean caption "
@@ -464,7 +481,8 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = B * F_ACC * world / (elapsed / args.steps)
         # forward passes per pair: 1 (+1 recompute with grad checkpointing) (+1 no_grad feature pass with accumulation) + 2 for the backward
-        flops_pair = FWD_GFLOP_PER_PAIR.get(args.model, 0.0) * (3 + (1 if args.grad_checkpointing else 0) + (1 if F_ACC > 1 else 0))
+        # (the recompute counts for the share of the towers' block FLOPs that is actually recomputed: --keep-blocks)
+        flops_pair = FWD_GFLOP_PER_PAIR.get(args.model, 0.0) * (3 + (recompute_share if args.grad_checkpointing else 0) + (1 if F_ACC > 1 else 0))
         line = {
             "metric": ("image-text pairs/sec (whole node), ViT-B-32 gbs=32768 at 1/2/4/8 GPUs" if args.model == "ViT-B-32" and not args.siglip
                        else f"image-text pairs/sec (whole node), {args.model}{' SigLIP' if args.siglip else ''}"), "value": round(value, 1),
@@ -484,6 +502,9 @@ def main():
                        "text_tower": text_rows_note,
                        "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
                        "last_block": last_block_note,
+                       "grad_checkpointing": (f"block recompute (transformer.py:577-585) for all but the last {kept_blocks[0]} image / {kept_blocks[1]} text blocks, whose "
+                                              f"activations stay in HBM (--keep-blocks {args.keep_blocks}); {recompute_share:.2f} of a forward is recomputed per step"
+                                              if args.grad_checkpointing else "off"),
                        "random_init_weights": True, "final_loss": round(final_loss, 4)},
             # FLOPs of the model as the reference runs it (every caption padded to context_length); the packed text tower executes fewer
             ("step_model_tflops_per_gpu" if not model_ref.pack_text else "step_dense_equivalent_model_tflops_per_gpu"): round(value / world * flops_pair / 1e3, 1),

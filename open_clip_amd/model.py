@@ -597,23 +597,30 @@ class Transformer(nn.Module):  # transformer.py:476-585
         self.width, self.layers = width, layers
         self.resblocks = nn.ModuleList([ResidualAttentionBlock(width, heads, mlp_ratio, quick_gelu) for _ in range(layers)])
         self.grad_checkpointing = False
+        self.keep_last_blocks = 0
 
     def get_cast_dtype(self):  # transformer.py:537-538
         return self.resblocks[0].get_weight_dtype()
 
-    def set_grad_checkpointing(self, enable=True, impl="inline"):
+    def set_grad_checkpointing(self, enable=True, impl="inline", keep_last=0):
+        """transformer.py:577-585 recomputes EVERY block in the backward.  ``keep_last`` = n (native extension) keeps the activations of
+        the last n blocks -- the ones whose backward runs first, so their memory is free again when the recompute of the earlier
+        blocks needs its transient -- and recomputes only the others: same results, and 288 GB of HBM hold far more than one block
+        input per layer (``NativeCLIP.plan_grad_checkpointing`` sizes n for a batch)."""
         self.grad_checkpointing = enable
+        self.keep_last_blocks = max(0, int(keep_last))
 
     def forward(self, x, cache, B, L, causal, seq_off=None, pooled_rows=None):
         """``pooled_rows`` (int32 [B], absolute rows): the caller only reads these rows of the output -- the last block then runs as
         _PooledBlockFn and the result is [B, C] (the pooled rows, in order) instead of [M, C]"""
         rc = self.grad_checkpointing and torch.is_grad_enabled()
         blocks = list(self.resblocks)
+        first_kept = len(blocks) - (self.keep_last_blocks if rc else 0)  # blocks from here on keep their activations
         last = blocks.pop() if pooled_rows is not None else None
-        for r in blocks:
-            x = r(x, cache, B, L, causal, rc, seq_off)
+        for i, r in enumerate(blocks):
+            x = r(x, cache, B, L, causal, rc and i < first_kept, seq_off)
         if last is not None:
-            x = last(x, cache, B, L, causal, rc, seq_off, pooled_rows)
+            x = last(x, cache, B, L, causal, rc and len(blocks) < first_kept, seq_off, pooled_rows)
         return x
 
 
@@ -677,8 +684,8 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         self.preprocess_cfg = {"size": (image_size, image_size), "mode": "RGB", "mean": self.image_mean, "std": self.image_std,
                                "interpolation": "bicubic", "resize_mode": "shortest", "fill_color": 0}
 
-    def set_grad_checkpointing(self, enable=True, impl="inline"):
-        self.transformer.set_grad_checkpointing(enable, impl)
+    def set_grad_checkpointing(self, enable=True, impl="inline", keep_last=0):
+        self.transformer.set_grad_checkpointing(enable, impl, keep_last)
 
     def no_weight_decay(self):  # transformer.py:745-751
         return {"positional_embedding", "class_embedding"}
@@ -857,9 +864,37 @@ class NativeCLIP(nn.Module):
         assert freeze_layer_norm, "Unfreezing LayerNorm is not supported. LayerNorm treated like other weights."  # model.py:373-375
         _lock_layer_groups(self.text_layer_groups(pooler_in_head), unlocked_layers)
 
-    def set_grad_checkpointing(self, enable=True, impl="inline"):
-        self.visual.set_grad_checkpointing(enable, impl)
-        self.transformer.set_grad_checkpointing(enable, impl)
+    def set_grad_checkpointing(self, enable=True, impl="inline", keep_last=0):
+        """model.py:377-379.  ``keep_last`` (native extension; an int for both towers or (image, text)): the last n blocks of a tower keep
+        their activations instead of being recomputed (Transformer.set_grad_checkpointing)"""
+        kv, kt = (keep_last, keep_last) if isinstance(keep_last, int) else keep_last
+        self.visual.set_grad_checkpointing(enable, impl, kv)
+        self.transformer.set_grad_checkpointing(enable, impl, kt)
+
+    def activation_bytes_per_block(self, batch_size: int, text_rows=None):
+        """(image, text) bytes one residual block saves for the backward when it is NOT recomputed: per row of width C the fp32 block
+        output (4C), ln_1 / ln_2 outputs (2C + 2C), qkv (6C), the attention output (2C), the fp32 middle of the residual stream (4C), the
+        8-bit gelu' (4C) and the MLP activation (8C) = 32 C, + the attention row statistics.  A recomputed block keeps its 4C input only.
+        ``text_rows``: rows of the packed text batch (default: every one of ``context_length`` positions)."""
+        v, t = self.visual, self.transformer
+        rows_v = batch_size * (v.grid_size[0] * v.grid_size[1] + 1)
+        rows_t = batch_size * self.context_length if text_rows is None else int(text_rows)
+        per = lambda rows, tr: rows * (32 * tr.width + 4 * tr.resblocks[0].n_head + 8)
+        return per(rows_v, v.transformer), per(rows_t, t)
+
+    def plan_grad_checkpointing(self, batch_size: int, budget_bytes: int, text_rows=None):
+        """switch block recompute on and keep the activations of as many blocks as ``budget_bytes`` hold: the text tower's first (few
+        rows once packed), then the image tower's.  Counted against the budget:
+        32 C bytes per row for a kept block, 4 C for a recomputed one, and two blocks' worth of the larger tower for the transients of
+        the backward (one block being recomputed + the gradients in flight).  Returns (image blocks kept, text blocks kept)."""
+        bv, bt = self.activation_bytes_per_block(batch_size, text_rows)
+        nv, nt = len(self.visual.transformer.resblocks), len(self.transformer.resblocks)
+        left = int(budget_bytes) - 2 * max(bv, bt) - (nv * bv + nt * bt) // 8  # every block input is held either way
+        kt = max(0, min(nt, left // max(1, bt - bt // 8)))
+        left -= kt * (bt - bt // 8)
+        kv = max(0, min(nv, left // max(1, bv - bv // 8)))
+        self.set_grad_checkpointing(True, keep_last=(kv, kt))
+        return kv, kt
 
     def no_weight_decay(self):
         return {"positional_embedding"} | {"visual." + n for n in self.visual.no_weight_decay()}

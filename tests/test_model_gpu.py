@@ -91,17 +91,22 @@ def test_vitb32_b8_against_reference_golden():
     _compare("vitb32_b8", g, model, out, loss)
 
 
-@pytest.mark.parametrize("cfg_name,B,ckpt", [("small-test", 9, False), ("small-test", 16, True)])
+@pytest.mark.parametrize("cfg_name,B,ckpt", [("small-test", 9, False), ("small-test", 16, True), ("small-test", 16, (1, 2))])
 def test_against_cpu_oracle(cfg_name, B, ckpt):
     """fresh seeded inputs (odd batch, patch 16, 3 text heads, ragged EOT positions), oracle on the host CPU;
-    also with block recompute (set_grad_checkpointing), which must not change anything"""
+    also with block recompute (set_grad_checkpointing) and with recompute of all but the last 1 image / 2 text blocks (keep_last), which
+    must not change anything"""
     from oracle import clip_oracle as O
     cfg = get_model_config(cfg_name)
     state = init_state_dict(cfg, seed=21, perturb=True)
     batch = synthetic_batch(cfg, B, seed=77)
     outs, grads = O.train_forward_backward(batch["image"], batch["text"], state, cfg)
     model = _build(cfg, state)
-    model.set_grad_checkpointing(ckpt)
+    if isinstance(ckpt, tuple):
+        model.set_grad_checkpointing(True, keep_last=ckpt)
+        ckpt = 2
+    else:
+        model.set_grad_checkpointing(ckpt)
     out, loss = _step(model, batch)
     fi = float((out["image_features"].float().cpu() - outs["image_features"]).abs().max())
     ft = float((out["text_features"].float().cpu() - outs["text_features"]).abs().max())
