@@ -333,7 +333,7 @@ def main():
         text_rows_note = f"dense: all {ctx_len} positions of every caption (as the reference)"
     from open_clip_amd.model import _pooled_last_block_ok
     last_block_note = ("out-projection, LN2 and MLP of each tower's last block on the pooled rows only (the only rows the poolers read; same features and "
-                       "gradients, tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); OCN_POOLED_LAST_BLOCK=0 runs every row"
+                       "gradients, tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); pooled_last_block=False runs every row"
                        if (_pooled_last_block_ok(model) and _pooled_last_block_ok(model.visual)) else "every row (as the reference)")
     pipe = None
     if args.h2d:

@@ -28,6 +28,17 @@ def main():
     print(f"{'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}  kernel")
     for n, (k, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:7d} {t / 1e6:10.3f} {t / k / 1e3:10.2f} {100.0 * t / tot:6.2f}  {n}")
+    # how many kernels share the chip, over the busiest contiguous stretch (the timed steps: from the first dispatch of the second half
+    # of the trace to the last one): time with 0 / 1 / 2 / 3+ kernels in flight
+    half = rows[len(rows) // 2:]
+    ev = sorted([(s, 1) for _, s, _ in half] + [(e, -1) for _, _, e in half])
+    depth, last, hist = 0, ev[0][0], {}
+    for t, d in ev:
+        hist[min(depth, 3)] = hist.get(min(depth, 3), 0) + (t - last)
+        depth, last = depth + d, t
+    whole = sum(hist.values())
+    print("# second half of the trace (%.1f ms): " % (whole / 1e6) + ", ".join(
+        f"{'3+' if k == 3 else k} kernel{'s' if k != 1 else ''} in flight {100.0 * v / whole:.1f} %" for k, v in sorted(hist.items())))
 
 
 if __name__ == "__main__":
