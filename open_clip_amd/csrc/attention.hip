@@ -745,7 +745,7 @@ extern "C" int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, in
     OCN_CHECK_ARG(qkv && out && lse && B > 0 && L > 0 && H > 0, "ocn_attn_fwd_hd: bad arguments");
     const int rc = ocn_launch_attn_generic_fwd(qkv, out, lse, B, L, H, head_dim, causal, scale, (hipStream_t)stream);
     if (rc == 1) {
-        ocn_set_error("ocn_attn_fwd_hd: head_dim=%d, L=%d unsupported (head_dim in {64,80,96,128}; K and V of a head must fit 160 KiB of LDS)", head_dim, L);
+        ocn_set_error("ocn_attn_fwd_hd: head_dim=%d, L=%d unsupported (head_dim in {64,80,88,96,104,112,128}; K and V of a head must fit 160 KiB of LDS)", head_dim, L);
         return OCN_ERR_UNSUPPORTED;
     }
     OCN_CHECK_LAUNCH("ocn_attn_fwd_hd");
@@ -758,7 +758,7 @@ extern "C" int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dou
     OCN_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "ocn_attn_bwd_hd: bad arguments");
     const int rc = ocn_launch_attn_generic_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, L, H, head_dim, causal, scale, (hipStream_t)stream);
     if (rc == 1) {
-        ocn_set_error("ocn_attn_bwd_hd: head_dim=%d, L=%d unsupported (head_dim in {64,80,96,128}; Q and dO of a head must fit 160 KiB of LDS)", head_dim, L);
+        ocn_set_error("ocn_attn_bwd_hd: head_dim=%d, L=%d unsupported (head_dim in {64,80,88,96,104,112,128}; Q and dO of a head must fit 160 KiB of LDS)", head_dim, L);
         return OCN_ERR_UNSUPPORTED;
     }
     OCN_CHECK_LAUNCH("ocn_attn_bwd_hd");

@@ -1,6 +1,7 @@
-// Generic multi-head self-attention core: any head_dim D in {64, 80, 96, 128} and ANY sequence length -- the path of the ViT-H-14 image
-// tower (head_dim 80, 257 tokens; BASELINE config 5) and of every head_dim-64 tower beyond 128 tokens (ViT-L-14's 257: config 4), which
-// the head-resident kernels of attention.hip (head_dim 64, a whole head in LDS) serve badly or not at all.
+// Generic multi-head self-attention core: any head_dim D in {64, 80, 88, 96, 104, 112, 128} and ANY sequence length -- the path of the
+// ViT-H-14 image tower (head_dim 80, 257 tokens; BASELINE config 5), of every head_dim-64 tower beyond 128 tokens (ViT-L-14's 257: config
+// 4) and of ViT-g-14 / ViT-bigG-14 / ViT-e-14 (head_dim 88 / 104 / 112), which the head-resident kernels of attention.hip (head_dim 64, a
+// whole head in LDS) serve badly or not at all.
 //
 // Same arithmetic as attention.hip (swapped products S^T = K Q^T, O^T = V^T P^T so that softmax statistics are lane-local, fp32
 // softmax in the exp2 domain, causal mask as a predicate, backward recomputes P from the saved LSE).  Residency is what differs
@@ -16,6 +17,9 @@
 //     bank quads for every supported D; transposed operands (V^T, K^T, Q^T, dO^T) come from the same image by ds_read_b64_tr_b16;
 //   * D = 80 needs no padding of the contraction (5 MFMA k-steps of 16); as an OUTPUT dimension it is covered by three 32-wide blocks
 //     whose last 16 columns multiply whatever follows the row in LDS and are never stored;
+//   * D = 88 / 104 (8 short of a k-step): the contraction runs over DP = 96 / 112 with the missing 8 d's ZERO on both sides -- the
+//     16-byte piece behind every LDS row is zeroed once (the chunk writes never touch it), and a wave's own rows, which come straight
+//     from global memory, get a zero fragment half instead of the neighbouring head's columns;
 //   * workgroups of one head are adjacent in the grid (they share K / V resp. Q / dO through the Infinity Cache);
 //   * the backward is three launches (dQ, dV, dK) that exchange delta[q] = sum_d dO O through a caller-provided fp32 workspace.
 #include "ocn_common.h"
@@ -28,10 +32,13 @@ constexpr int CH = 64;  // rows per streamed chunk (two 32-row blocks)
 
 template <int D>
 struct Geo {
-    static constexpr int CPR = D / 8;               // 16-byte pieces per row
-    static constexpr int PITCH = D * 2 + 16;        // LDS row pitch in bytes
+    static_assert(D % 8 == 0, "head_dim must be a multiple of 8 (16-byte pieces)");
+    static constexpr int DP = (D + 15) / 16 * 16;   // contraction length: D rounded up to whole MFMA k-steps (zero padded)
+    static constexpr bool PADDED = DP != D;
+    static constexpr int CPR = D / 8;               // 16-byte pieces per row (the ones that exist in global memory)
+    static constexpr int PITCH = DP * 2 + 16;       // LDS row pitch in bytes
     static constexpr int DB = (D + 31) / 32;        // 32-wide output blocks over d
-    static constexpr int KS = D / 16;               // MFMA k-steps over d
+    static constexpr int KS = DP / 16;              // MFMA k-steps over d
     static constexpr int PIECES = CH * CPR;         // 16-byte pieces per chunk image
     static constexpr int PPT = (PIECES + 255) / 256;  // pieces per thread
     static constexpr int BUF = CH * PITCH;          // bytes per chunk image
@@ -93,15 +100,36 @@ OCN_DEV void write_chunk(char* sT, const bf16x8 (&r)[Geo<D>::PPT]) {
     }
 }
 
+// D = 88 / 104: the 16-byte piece behind the D columns of every row of `nimg` chunk images (`stride` bytes apart) <- 0, once per kernel
+template <int D>
+OCN_DEV void zero_pad_pieces(char* img0, int stride, int nimg) {
+    using G = Geo<D>;
+    if constexpr (G::PADDED) {
+        const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4_t){0u, 0u, 0u, 0u});
+        for (int i = threadIdx.x; i < nimg * CH; i += 256) *(bf16x8*)(img0 + (i / CH) * stride + (i % CH) * G::PITCH + G::CPR * 16) = z;
+    }
+}
+
 // d-contiguous operand: row `row` of a chunk image, k-step s (16 of the d's), this lane's 8 d's
 template <int PITCH>
 OCN_DEV bf16x8 frag_rows_p(const char* sT, int row, int s, int lane) {
     return *(const bf16x8*)(sT + row * PITCH + ((s * 2 + (lane >> 5)) << 4));
 }
 
-// the same fragment taken straight from global memory (row-major, `rs` elements per row)
+// the same fragment taken straight from global memory (row-major, `rs` elements per row).  D = 88 / 104: the upper half of the last
+// k-step lies behind the head's columns -- zero, loaded from the last piece that exists (never past the row)
+template <int D>
 OCN_DEV bf16x8 frag_rows_g(const bf16* __restrict__ base, size_t rs, int row, int s, int lane) {
-    return *(const bf16x8*)(base + (size_t)row * rs + (s * 2 + (lane >> 5)) * 8);
+    using G = Geo<D>;
+    int piece = s * 2 + (lane >> 5);
+    if constexpr (G::PADDED) {
+        const bool beyond = piece >= G::CPR;
+        piece = beyond ? G::CPR - 1 : piece;
+        const bf16x8 v = *(const bf16x8*)(base + (size_t)row * rs + piece * 8);
+        const bf16x8 z = __builtin_bit_cast(bf16x8, (u32x4_t){0u, 0u, 0u, 0u});
+        return beyond ? z : v;
+    }
+    return *(const bf16x8*)(base + (size_t)row * rs + piece * 8);
 }
 
 // transposed operand: A[i = d (dblk*32 + lane&31)][k-slots <-> rows rbase + 16t + 8(e>>2) + 4h + (e&3)]  (cf. attention.hip)
@@ -172,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_fwd_kernel(const bf16* __restri
     const int qrow = query < L ? query : L - 1;
     bf16x8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = frag_rows_g(qbase, rs, qrow, s, lane);
+    for (int s = 0; s < KS; ++s) qf[s] = frag_rows_g<D>(qbase, rs, qrow, s, lane);
     // key blocks this WORKGROUP walks (causal: up to its last query block) and this wave needs
     const int wg_nkb = causal ? min(nblk, grp * 4 + 4) : nblk;
     const int my_nkb = qb >= nblk ? 0 : (causal ? qb + 1 : nblk);
@@ -180,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_fwd_kernel(const bf16* __restri
     bf16x8 rk[G::PPT], rv[G::PPT];
     load_chunk<D>(kbase, rs, 0, L, rk);
     load_chunk<D>(vbase, rs, 0, L, rv);
+    zero_pad_pieces<D>(smem, G::BUF, 4);
     write_chunk<D>(smem, rk);
     write_chunk<D>(smem + G::BUF, rv);
     __syncthreads();
@@ -296,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_dq_kernel(const bf16* __res
     float delta_q = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        qf[s] = frag_rows_g(qbase, rs, qrow, s, lane);
-        dof[s] = frag_rows_g(dobase, (size_t)C, qrow, s, lane);
-        const bf16x8 of = frag_rows_g(obase, (size_t)C, qrow, s, lane);
+        qf[s] = frag_rows_g<D>(qbase, rs, qrow, s, lane);
+        dof[s] = frag_rows_g<D>(dobase, (size_t)C, qrow, s, lane);
+        const bf16x8 of = frag_rows_g<D>(obase, (size_t)C, qrow, s, lane);
 #pragma unroll
         for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[e]);
     }
@@ -311,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_dq_kernel(const bf16* __res
     bf16x8 rk[G::PPT], rv[G::PPT];
     load_chunk<D>(kbase, rs, 0, L, rk);
     load_chunk<D>(vbase, rs, 0, L, rv);
+    zero_pad_pieces<D>(smem, G::BUF, 4);
     write_chunk<D>(smem, rk);
     write_chunk<D>(smem + G::BUF, rv);
     __syncthreads();
@@ -411,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_dkv_kernel(const bf16* __re
     bf16x8 kf[KS], vf[DV ? 1 : KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        kf[s] = frag_rows_g(qbase + C, rs, krow, s, lane);
-        if constexpr (!DV) vf[s] = frag_rows_g(qbase + 2 * C, rs, krow, s, lane);
+        kf[s] = frag_rows_g<D>(qbase + C, rs, krow, s, lane);
+        if constexpr (!DV) vf[s] = frag_rows_g<D>(qbase + 2 * C, rs, krow, s, lane);
     }
     // query chunks this workgroup walks: causal -> from its first key block on
     const int c0 = causal ? (grp * 4) / 2 : 0;
@@ -430,6 +460,8 @@ __global__ __launch_bounds__(256, 2) void attn_s_bwd_dkv_kernel(const bf16* __re
     load_chunk<D>(qbase, rs, c0 * CH, L, rq);
     load_chunk<D>(dobase, (size_t)C, c0 * CH, L, rd);
     load_stats(c0 * CH);
+    zero_pad_pieces<D>(smem, G::BUF, 2);
+    zero_pad_pieces<D>(smem + SLOT, G::BUF, 2);
     write_chunk<D>(smem, rq);
     write_chunk<D>(smem + G::BUF, rd);
     write_stats(smem);
@@ -554,6 +586,9 @@ int ocn_launch_attn_generic_fwd(const void* qkv, void* out, float* lse, int B, i
     switch (D) {
         case 64: return launch_fwd<64>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
         case 80: return launch_fwd<80>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
+        case 88: return launch_fwd<88>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
+        case 104: return launch_fwd<104>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
+        case 112: return launch_fwd<112>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
         case 96: return launch_fwd<96>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
         case 128: return launch_fwd<128>((const bf16*)qkv, (bf16*)out, lse, B, L, H, causal, scale, st);
     }
@@ -565,6 +600,9 @@ int ocn_launch_attn_generic_bwd(const void* qkv, const void* out, const void* do
     switch (D) {
         case 64: return launch_bwd<64>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
         case 80: return launch_bwd<80>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
+        case 88: return launch_bwd<88>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
+        case 104: return launch_bwd<104>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
+        case 112: return launch_bwd<112>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
         case 96: return launch_bwd<96>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
         case 128: return launch_bwd<128>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, delta, B, L, H, causal, scale, st);
     }

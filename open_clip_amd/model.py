@@ -729,6 +729,9 @@ class VisionTransformer(nn.Module):  # transformer.py:592-928 (default path: lea
         return _HeadFn.apply(x, self.ln_post.weight, self.ln_post.bias, self.proj, None, self._cache, B, T, normalize)
 
 
+ATTENTION_HEAD_DIMS = (64, 80, 88, 96, 104, 112, 128)  # instantiations of csrc/attention_generic.hip (64 also: csrc/attention.hip)
+
+
 class NativeCLIP(nn.Module):
     """Drop-in for ``open_clip.model.CLIP`` (model.py:318-548) on the ViT + causal-text path."""
 
@@ -780,8 +783,8 @@ class NativeCLIP(nn.Module):
         self.embed_dim = embed_dim
         head_width = v.get("head_width", 64)
         for hd in (head_width, t["width"] // t["heads"]):
-            if hd not in (64, 80, 96, 128):
-                raise NotImplementedError(f"the native attention kernels support head_dim 64 / 80 / 96 / 128 (got {hd})")
+            if hd not in ATTENTION_HEAD_DIMS:
+                raise NotImplementedError(f"the native attention kernels support head_dim {' / '.join(map(str, ATTENTION_HEAD_DIMS))} (got {hd})")
         # `quick_gelu` (model.py:172-176, :262): QuickGELU instead of nn.GELU in the MLPs of BOTH towers (ViT-B-32-quickgelu.json: the
         # OpenAI / LAION-400M checkpoints)
         self.quick_gelu = bool(quick_gelu)

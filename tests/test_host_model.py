@@ -81,7 +81,7 @@ def test_create_model_rejects_unsupported():
     odd = get_model_config("tiny-test")
     odd["vision_cfg"].update(width=144, head_width=72)
     add_model_config("odd-head", odd)
-    with pytest.raises(NotImplementedError, match="head_dim 64 / 80 / 96 / 128"):
+    with pytest.raises(NotImplementedError, match="head_dim 64 / 80 / 88 / 96 / 104 / 112 / 128"):
         create_model("odd-head", device="meta")
     with pytest.raises(ValueError, match="precision"):
         create_model("tiny-test", precision="fp16", device="cpu")

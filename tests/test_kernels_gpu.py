@@ -324,10 +324,14 @@ def test_attention(dev, B, L, H, causal):
 @pytest.mark.parametrize("B,L,H,D,causal,force", [(2, 257, 2, 80, False, False), (3, 50, 3, 80, False, False), (2, 77, 2, 80, True, False),
                                                  (1, 257, 1, 128, False, False), (2, 40, 2, 96, True, False), (1, 400, 2, 64, False, False),
                                                  (2, 400, 1, 64, True, False), (3, 50, 2, 64, False, True), (2, 77, 3, 64, True, True), (4, 7, 2, 80, True, False),
-                                                 (2, 257, 2, 64, False, False), (1, 200, 2, 64, True, False), (3, 257, 2, 64, False, True)])
+                                                 (2, 257, 2, 64, False, False), (1, 200, 2, 64, True, False), (3, 257, 2, 64, False, True),
+                                                 (2, 257, 2, 88, False, False), (2, 77, 3, 88, True, False), (1, 257, 2, 104, False, False),
+                                                 (3, 50, 1, 104, True, False), (2, 257, 1, 112, False, False), (2, 40, 2, 112, True, False),
+                                                 (1, 730, 2, 80, False, False), (3, 197, 6, 64, False, False), (3, 197, 2, 80, False, False)])
 def test_attention_generic_head_dims(dev, B, L, H, D, causal, force):
     """streamed kernels (csrc/attention_generic.hip: K / V resp. Q / dO in 64-row chunks through a two-slot LDS ring): head_dim 80 / 96 / 128
-    (ViT-H-14: 80 x 257 tokens), head_dim 64 beyond 320 tokens, the MIXED default dispatch of head_dim 64 between 129 and 320 tokens
+    (ViT-H-14: 80 x 257 tokens; 730 tokens at 378 px), 88 / 104 (ViT-g-14 / ViT-bigG-14: contraction zero-padded to 96 / 112 -- the random
+    columns of the neighbouring heads must not leak in) and 112 (ViT-e-14), head_dim 64 beyond 320 tokens, the MIXED default dispatch of head_dim 64 between 129 and 320 tokens
     (streamed forward, head-resident backward sharing its LSE: ViT-L-14's 257) and -- forced through developer knob 7 -- the head_dim-64
     shapes of the specialised kernels, which must agree with them.  Same tolerances as test_attention."""
     from open_clip_amd import _lib, ops

@@ -108,3 +108,42 @@ def test_layer_groups_and_partial_locks_match_the_reference():
         ref.lock_text_tower(unlocked_layers=k)
         native.lock_text_tower(unlocked_layers=k)
         assert {n for n, p in ref.named_parameters() if p.requires_grad} == {n for n, p in native.named_parameters() if p.requires_grad}, k
+
+
+def test_registered_configs_equal_the_reference_jsons(tmp_path):
+    """every reference-named config of the native registry carries exactly the reference JSON's values; every plain-ViT JSON the native
+    path can run is registered; add_model_config(path) (the reference's form, factory.py:80-85) loads JSON files"""
+    import glob
+    import json
+    import os
+    from open_clip_amd import configs
+    from open_clip_amd.model import NativeCLIP
+    ref_dir = "/root/reference/src/open_clip/model_configs"
+    names = [n for n in configs.list_models() if not n.endswith("-test")]
+    assert len(names) >= 27
+    for n in names:
+        with open(os.path.join(ref_dir, n + ".json")) as fh:
+            assert json.load(fh) == configs._MODEL_CONFIGS[n], n
+    # the other way round: a reference ViT config that passes the native path's own option check must be registered
+    missing = []
+    for f in sorted(glob.glob(os.path.join(ref_dir, "ViT-*.json"))):
+        d = json.load(open(f))
+        name = os.path.basename(f)[:-5]
+        kw = {k: v for k, v in d.items() if k not in ("embed_dim", "vision_cfg", "text_cfg", "quick_gelu")}
+        try:
+            NativeCLIP._check_cfg(d["vision_cfg"], d["text_cfg"], kw)
+        except NotImplementedError:
+            continue
+        hw = d["vision_cfg"].get("head_width", 64)
+        if hw % 8 == 0 and hw <= 128 and name not in names:
+            missing.append(name)
+    assert not missing, missing
+    # add_model_config(path)
+    p = tmp_path / "My-ViT.json"
+    p.write_text(json.dumps(configs._MODEL_CONFIGS["ViT-S-32"]))
+    (tmp_path / "notes.json").write_text(json.dumps({"comment": "not a model"}))
+    configs.add_model_config(str(tmp_path))
+    try:
+        assert configs.get_model_config("My-ViT")["vision_cfg"]["width"] == 384 and "notes" not in configs.list_models()
+    finally:
+        configs._MODEL_CONFIGS.pop("My-ViT", None)
