@@ -43,7 +43,7 @@ def code_identity():
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return sha, h.hexdigest()[:16]
-FWD_GFLOP_PER_PAIR = {"ViT-B-32": 14.78, "ViT-L-14": 175.33, "ViT-H-14": 381.68}  # docs/model_profile.csv (reference)
+FWD_GFLOP_PER_PAIR = {"ViT-B-32": 14.78, "ViT-L-14": 175.33, "ViT-H-14": 381.68}  # docs/model_profile.csv (reference); others: configs.forward_gflops_per_pair
 
 
 def parse():
@@ -482,7 +482,8 @@ def main():
         value = B * F_ACC * world / (elapsed / args.steps)
         # forward passes per pair: 1 (+1 recompute with grad checkpointing) (+1 no_grad feature pass with accumulation) + 2 for the backward
         # (the recompute counts for the share of the towers' block FLOPs that is actually recomputed: --keep-blocks)
-        flops_pair = FWD_GFLOP_PER_PAIR.get(args.model, 0.0) * (3 + (recompute_share if args.grad_checkpointing else 0) + (1 if F_ACC > 1 else 0))
+        from open_clip_amd.configs import forward_gflops_per_pair
+        flops_pair = FWD_GFLOP_PER_PAIR.get(args.model, forward_gflops_per_pair(cfg)) * (3 + (recompute_share if args.grad_checkpointing else 0) + (1 if F_ACC > 1 else 0))
         line = {
             "metric": ("image-text pairs/sec (whole node), ViT-B-32 gbs=32768 at 1/2/4/8 GPUs" if args.model == "ViT-B-32" and not args.siglip
                        else f"image-text pairs/sec (whole node), {args.model}{' SigLIP' if args.siglip else ''}"), "value": round(value, 1),

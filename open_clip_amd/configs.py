@@ -146,3 +146,21 @@ def count_params(cfg: dict) -> int:
     n += v["width"] * 3 * v["patch_size"] ** 2 + v["width"] + vision_tokens(cfg) * v["width"] + 4 * v["width"] + v["width"] * e
     n += t["vocab_size"] * t["width"] + t["context_length"] * t["width"] + 2 * t["width"] + t["width"] * e + 1
     return n
+
+
+def forward_gflops_per_pair(cfg: dict) -> float:
+    """algorithmic forward GFLOPs (2 x multiply-accumulates) of one image-text pair as the reference executes it (every caption padded to
+    context_length): per block and token (4 + 2 r) C^2 multiply-accumulates for QKV, out-projection and the MLP of ratio r, + 2 L C for the
+    two attention products; the patch embedding; the two projections.  Reproduces the `gflops` column of the reference's
+    docs/model_profile.csv for all 28 registered configs it lists to 0.1 % (tests/test_reference_dropin.py)."""
+    v, t, e = cfg["vision_cfg"], cfg["text_cfg"], cfg["embed_dim"]
+
+    def tower(width, layers, tokens, ratio):
+        per_token = (4 + 2 * ratio) * width * width + 2 * tokens * width
+        return layers * tokens * per_token
+
+    lv = vision_tokens(cfg)
+    macs = tower(v["width"], v["layers"], lv, int(v["width"] * v.get("mlp_ratio", 4.0)) / v["width"])
+    macs += (lv - 1) * v["width"] * 3 * v["patch_size"] ** 2 + v["width"] * e
+    macs += tower(t["width"], t["layers"], t["context_length"], int(t["width"] * t.get("mlp_ratio", 4.0)) / t["width"]) + t["width"] * e
+    return 2 * macs / 1e9

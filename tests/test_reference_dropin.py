@@ -147,3 +147,19 @@ def test_registered_configs_equal_the_reference_jsons(tmp_path):
         assert configs.get_model_config("My-ViT")["vision_cfg"]["width"] == 384 and "notes" not in configs.list_models()
     finally:
         configs._MODEL_CONFIGS.pop("My-ViT", None)
+
+
+def test_analytic_forward_flops_match_the_reference_profile_table():
+    """bench.py prices every model against the MFMA roof with configs.forward_gflops_per_pair: it must agree with the reference's own
+    docs/model_profile.csv (the figure SURVEY.md 8d quotes) for every registered config the table lists"""
+    import csv
+    from open_clip_amd import configs
+    with open("/root/reference/docs/model_profile.csv") as fh:
+        table = {r["model"]: float(r["gflops"]) for r in csv.DictReader(fh)}
+    seen = 0
+    for name in configs.list_models():
+        if name in table:
+            got = configs.forward_gflops_per_pair(configs.get_model_config(name))
+            assert abs(got / table[name] - 1) < 2e-3, (name, got, table[name])
+            seen += 1
+    assert seen >= 28
