@@ -9,6 +9,7 @@ Fixtures (all fp32 CPU, ``torch.use_deterministic_algorithms(True)``):
                      reference's features / logits / loss / parameter grads (``CLIP`` + ``ClipLoss``)
   tiny_siglip.npz    same model with logit_bias; ``SigLipLoss`` (world_size 1)
   tiny_quickgelu.npz same shape with ``quick_gelu=True`` (QuickGELU in both towers, layers.py:29-32)
+  tiny_hd88.npz      'hd88-test' config: image head_width 88 and mlp_ratio 4.3637 (ViT-g-14's shape class)
   vitb32_b8.npz      ViT-B-32, B=8; weights regenerated from ``init_state_dict(seed=0, perturb=True)``
                      (checksums stored), reference outputs + grad samples
   dist_loss_w2.npz   ``ClipLoss`` (3 gather modes) and ``SigLipLoss`` ('bidir') under gloo, world_size 2/3:
@@ -56,7 +57,7 @@ def ref_model(cfg, state, siglip=False):
     from open_clip.model import CLIP
 
     kw = dict(init_logit_scale=float(np.log(10)), init_logit_bias=-10.0) if siglip else {}
-    v = {k: cfg["vision_cfg"][k] for k in ("image_size", "layers", "width", "patch_size", "head_width") if k in cfg["vision_cfg"]}
+    v = {k: cfg["vision_cfg"][k] for k in ("image_size", "layers", "width", "patch_size", "head_width", "mlp_ratio") if k in cfg["vision_cfg"]}
     t = {k: cfg["text_cfg"][k] for k in ("context_length", "vocab_size", "width", "heads", "layers")}
     if cfg.get("quick_gelu"):
         kw["quick_gelu"] = True
@@ -124,6 +125,23 @@ def make_tiny_quickgelu():
     pack_grads(out, grads)
     np.savez_compressed(os.path.join(GOLD, "tiny_quickgelu.npz"), **out)
     print("tiny_quickgelu.npz loss", float(outs["loss"]))
+
+
+def make_tiny_hd88():
+    """head_width 88 / non-integer mlp_ratio (ViT-g-14.json): pins the oracle's (and the kernels') handling of both against the reference"""
+    cfg = get_model_config("hd88-test")
+    state = fp16_representable(init_state_dict(cfg, seed=9, perturb=True))
+    batch = synthetic_batch(cfg, 6, seed=97)
+    batch["image"] = batch["image"].half().float()
+    outs, grads = run_reference(cfg, state, batch)
+    out = {"image": batch["image"].numpy().astype(np.float16), "text": batch["text"].numpy()}
+    for k, v in state.items():
+        out["w/" + k] = v.numpy().astype(np.float16) if v.ndim > 0 else v.numpy().astype(np.float32)
+    for k, v in outs.items():
+        out["out/" + k] = v.detach().numpy()
+    pack_grads(out, grads)
+    np.savez_compressed(os.path.join(GOLD, "tiny_hd88.npz"), **out)
+    print("tiny_hd88.npz loss", float(outs["loss"]))
 
 
 def make_vitb32():
@@ -234,13 +252,15 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.use_deterministic_algorithms(True)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["tiny", "siglip", "quickgelu", "dist", "vitb32"]
+    which = sys.argv[1:] or ["tiny", "siglip", "quickgelu", "hd88", "dist", "vitb32"]
     if "tiny" in which:
         make_tiny(False)
     if "siglip" in which:
         make_tiny(True)
     if "quickgelu" in which:
         make_tiny_quickgelu()
+    if "hd88" in which:
+        make_tiny_hd88()
     if "dist" in which:
         make_dist(2, 29611)
         make_dist(3, 29612)

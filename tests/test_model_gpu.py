@@ -67,10 +67,10 @@ def _compare(tag, g, model, out, loss):
         assert rel <= _grad_tol(n, gmax, grads[k].ndim), (k, rel, n)
 
 
-@pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True), ("tiny_quickgelu.npz", False)])
+@pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True), ("tiny_quickgelu.npz", False), ("tiny_hd88.npz", False)])
 def test_tiny_against_reference_golden(name, siglip):
     g = load(name)
-    cfg = get_model_config("tiny-test")
+    cfg = get_model_config("hd88-test" if "hd88" in name else "tiny-test")  # hd88: head_width 88 + mlp_ratio 4.3637 (ViT-g-14's shape class)
     # tiny_quickgelu: the reference's CLIP(quick_gelu=True) -- the `*-quickgelu` configs of the OpenAI / LAION-400M checkpoints
     model = _build(cfg, state_from_golden(g), siglip, **({"quick_gelu": True} if "quickgelu" in name else {}))
     batch = {"image": torch.from_numpy(g["image"].astype(np.float32)), "text": torch.from_numpy(g["text"])}

@@ -18,10 +18,10 @@ def _close(a, b, tol=TOL):
     return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True), ("tiny_quickgelu.npz", False)])
+@pytest.mark.parametrize("name,siglip", [("tiny_clip.npz", False), ("tiny_siglip.npz", True), ("tiny_quickgelu.npz", False), ("tiny_hd88.npz", False)])
 def test_tiny_forward_backward_matches_reference(name, siglip):
     g = load(name)
-    cfg = get_model_config("tiny-test")
+    cfg = get_model_config("hd88-test" if "hd88" in name else "tiny-test")  # hd88: head_width 88, mlp_ratio 4.3637 (ViT-g-14's shape class)
     if "quickgelu" in name:  # reference CLIP(quick_gelu=True): QuickGELU in both towers (layers.py:29-32)
         cfg["quick_gelu"] = True
     state = state_from_golden(g)
