@@ -17,6 +17,7 @@ if has newtests; then
   timeout 900 python -m pytest ${NEW_TESTS:-tests/test_bench_size_gpu.py} -q --maxfail=12 --durations=10 2>&1 | tail -40 > $O/${TAG}_newtests.log
   cp $O/parity_report.txt $O/${TAG}_newtests_parity_report.txt 2>/dev/null; stamp newtests
 fi
+if [ ! -d $GRAFT_REPO_ROOT/_ab_r02 ]; then STEPS=$(echo " $STEPS " | sed 's/ abgelu / /; s/ abstep / /'); fi  # the round-2 tree (untracked) is needed for the A/B steps
 if has abgelu; then  # GELU / dGELU epilogue GEMMs: this tree (8-bit gelu') against the round-2 tree (bf16 gelu'), alternating
   for i in 1 2; do
     timeout 200 python tools/ab_gelu_epilogues.py >> $O/${TAG}_abgelu_new.txt 2>&1
