@@ -85,10 +85,10 @@ _MODEL_CONFIGS = {
         "text_cfg": {"context_length": 77, "vocab_size": 1024, "width": 128, "heads": 2, "layers": 2},
     },
     # ViT-g-14's shape class in miniature: image head_dim 88 (contraction zero-padded to 96 in the attention kernels), MLP width
-    # int(176 * 4.3637) = 768, patch 14, 26 tokens
+    # int(352 * 4.3637) = 1536, patch 14, 26 tokens (widths are multiples of 32: the GEMM kernels' K granularity)
     "hd88-test": {
         "embed_dim": 96,
-        "vision_cfg": {"image_size": 70, "layers": 2, "width": 176, "head_width": 88, "mlp_ratio": 4.3637, "patch_size": 14},
+        "vision_cfg": {"image_size": 70, "layers": 1, "width": 352, "head_width": 88, "mlp_ratio": 4.3637, "patch_size": 14},
         "text_cfg": {"context_length": 77, "vocab_size": 1024, "width": 128, "heads": 2, "layers": 2},
     },
     "small-test": {
