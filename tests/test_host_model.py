@@ -301,3 +301,38 @@ def test_partial_recompute_plan():
     used = kv * bv + (nv - kv) * bv // 8 + kt * bt + (nt - kt) * bt // 8 + 2 * max(bv, bt)
     assert used <= 228 * 10 ** 9
     assert model.visual.transformer.grad_checkpointing and model.visual.transformer.keep_last_blocks == kv
+
+
+def test_host_text_plan_layout():
+    """input_pipeline.HostTextPlan (the packed text layout computed next to the tokenizer) against a plain loop: rows up to the FIRST
+    maximum of every caption (text_global_pool's argmax, transformer.py:941-944), their positions, the cumulative offsets, the bucket order
+    (stable by 32-row block count) and the count of out-of-vocabulary ids"""
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.input_pipeline import HostTextPlan
+    from open_clip_amd.synth import synthetic_batch
+    cfg = get_model_config("ViT-B-32")
+    text = synthetic_batch(cfg, 37, seed=3)["text"]
+    text[5, 3] = text[5].max()          # a tie: the first maximum wins
+    text[7, 2] = 60000                  # an id outside the vocabulary (it is also the row's maximum)
+    plan = HostTextPlan(text, cfg["text_cfg"]["vocab_size"], buckets=True)
+    B, L = text.shape
+    eot, toks, pos, off = [], [], [], [0]
+    for b in range(B):
+        row = text[b].tolist()
+        e = row.index(max(row))
+        eot.append(e)
+        toks += row[:e + 1]
+        pos += list(range(e + 1))
+        off.append(off[-1] + e + 1)
+    assert eot[5] == 3 and eot[7] == 2 and plan.n_bad == 1 and plan.M == off[-1]
+    v = plan.device_views(plan.ints, plan.tokens)     # host tensors stand in for the device copies
+    assert v["eot"].tolist() == eot and v["seq_off"].tolist() == off and v["last_row"].tolist() == [o - 1 for o in off[1:]]
+    assert v["tokens"].tolist() == toks and v["posidx"].tolist() == pos
+    nb = [(e + 1 + 31) // 32 for e in eot]
+    order = v["order"].tolist()
+    assert sorted(order) == list(range(B)) and [nb[i] for i in order] == sorted(nb)
+    assert all(a < b for a, b in zip(order, order[1:]) if nb[a] == nb[b])           # stable inside a bucket
+    assert v["counts"] == [nb.count(k) for k in range(1, (L + 31) // 32 + 1)] and sum(v["counts"]) == B
+    assert plan.ints.numel() <= HostTextPlan.capacity(B, L)
+    flat = HostTextPlan(text, None, buckets=False)
+    assert flat.device_views(flat.ints, flat.tokens)["order"] is None and flat.counts is None and flat.n_bad == 0
