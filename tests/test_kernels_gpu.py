@@ -321,6 +321,45 @@ def test_attention(dev, B, L, H, causal):
         check(tag + f" d{nm}", dqkv[:, i * C:(i + 1) * C], x.grad[:, i * C:(i + 1) * C], rel=2e-2)
 
 
+@pytest.mark.parametrize("L,causal,packed", [(50, False, False), (77, True, False), (77, True, True), (100, False, False)])
+def test_attention_backward_padded_rows_stay_finite(dev, L, causal, packed):
+    """padded rows of the head-resident kernels (the tail of a sequence's last 32-row block) must never reach a result.  Adversarial case:
+    the LAST row's scores are all ~ -240 (its saved LSE is ~ -236): P of a padded key / query evaluated against that LSE is exp(+236) = inf,
+    and an implementation that annihilates padded entries by a zero factor instead of a predicate would produce inf x 0 = NaN for every
+    gradient of the head (the mask-free backward tried in round 3 needed a clamp on P for exactly this case)."""
+    from open_clip_amd import ops
+    B, H = 3, 2
+    C = H * 64
+    g = torch.Generator().manual_seed(L)
+    lens = [L, L - 7, max(3, L - 40)] if packed else [L] * B
+    rows = sum(lens)
+    qkv = bf(torch.randn(rows, 3 * C, generator=g) * 1.5)
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    for b in range(B):  # last query of every sequence: q = 30, all keys get a -1 component sum -> S = -1920 * 0.125
+        qkv[off[b + 1] - 1, 0:C] = 30.0
+        qkv[off[b]:off[b + 1], C:2 * C] = -1.0
+    qkv = bf(qkv).to(dev)
+    dout = bf(torch.randn(rows, C, generator=g)).to(dev)
+    lay = None
+    if packed:
+        so = torch.tensor(off, dtype=torch.int32, device=dev)
+        nb = torch.tensor([(n + 31) // 32 for n in lens])
+        lay = ops.SeqLayout(so, torch.sort(nb, stable=True).indices.to(torch.int32).to(dev), torch.bincount(nb - 1, minlength=(L + 31) // 32).tolist())
+    out, lse = ops.attn_fwd(qkv, B, L, H, causal, 0.125, seq_off=lay)
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, B, L, H, causal, 0.125, seq_off=lay)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all()
+    # reference per sequence (fp32)
+    for b in range(B):
+        x = qkv[off[b]:off[b + 1]].float().requires_grad_(True)
+        ref, _ = _attn_ref(x, 1, lens[b], H, causal)
+        ref.backward(dout[off[b]:off[b + 1]].float())
+        tag = f"attn_padded[L{L} c{int(causal)} p{int(packed)} seq{b}]"
+        check(tag + " out", out[off[b]:off[b + 1]], ref.detach(), rel=6e-3)
+        check(tag + " dqkv", dqkv[off[b]:off[b + 1]], x.grad, rel=2e-2)
+
+
 @pytest.mark.parametrize("B,L,H,D,causal,force", [(2, 257, 2, 80, False, False), (3, 50, 3, 80, False, False), (2, 77, 2, 80, True, False),
                                                  (1, 257, 1, 128, False, False), (2, 40, 2, 96, True, False), (1, 400, 2, 64, False, False),
                                                  (2, 400, 1, 64, True, False), (3, 50, 2, 64, False, True), (2, 77, 3, 64, True, True), (4, 7, 2, 80, True, False),
