@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--no-wgrad-pair", action="store_true", help="with --serial-towers: no wgrad side stream either (every kernel alone on the chip: the "
                     "configuration of the event-timed steps, used for the rocprofv3 / PMC passes)")
     ap.add_argument("--no-dense-text-line", action="store_true", help="skip the extra --dense-text timing that the default line carries")
+    ap.add_argument("--no-extra-lines", action="store_true", help="skip the two further samples the default line carries: `reference_work` (dense text tower AND "
+                    "full last blocks: exactly the rows the reference executes) and `accum8_gbs32768` (the metric's own global batch on one GPU, --accum-freq 8)")
     ap.add_argument("--dense-text", action="store_true", help="run all context_length positions of every caption through the text tower like the reference "
                     "does (default: packed -- only the tokens up to the pooled EOT exist; same features, loss and gradients, see model.py::_TextPack)")
     ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
@@ -373,24 +375,26 @@ def main():
 
     step_no = [0]
 
-    def micro_batches():
+    def micro_batches(mb):
         """device batches of this optimizer step; with --h2d each one arrives from pinned host memory while the previous one computes"""
-        for j in range(F_ACC):
+        for j in range(len(mb)):
             if pipe is None:
-                yield micro[j]
+                yield mb[j]
             else:
                 b = pipe.next()
-                pipe.submit(*host_pool[(step_no[0] * F_ACC + j + 1) % 2])  # next batch's copy runs under this batch's compute
+                pipe.submit(*host_pool[(step_no[0] * len(mb) + j + 1) % 2])  # next batch's copy runs under this batch's compute
                 yield b
 
-    def step():
+    def step(mb=None):
+        """one optimizer step over the micro-batches ``mb`` (default: the F_ACC batches of this run)"""
+        mb = micro if mb is None else mb
         # linear warm-up of the reference's schedule (scheduler.py:6-15: lr * (step + 1) / warmup_length)
         lr_t = args.lr * min(1.0, (step_no[0] + 1) / max(1, args.lr_warmup_steps))
         for g in opt.param_groups:
             g["lr"] = lr_t
         opt.zero_grad(set_to_none=True)
-        if F_ACC == 1:
-            b = next(iter(micro_batches()))
+        if len(mb) == 1:
+            b = next(iter(micro_batches(mb)))
             out = net(image=b["image"], text=b["text"])
             loss = loss_fn(**out)
             loss.backward()
@@ -401,7 +405,7 @@ def main():
         else:
             # train.py:236-311: features of every micro-batch under no_grad, then every micro-batch again with gradient, the loss taken
             # over the concatenation (cached features stand in for the other micro-batches)
-            held = list(micro_batches())
+            held = list(micro_batches(mb))
             feats = {"image_features": [], "text_features": []}
             with torch.no_grad():
                 for b in held:
@@ -477,6 +481,49 @@ def main():
         dense_text = {"value": round(B * F_ACC / td, 1), "unit": "pairs/s", "ms_per_step": round(td * 1e3, 2), "steps": n_dense,
                       "what": "same step with --dense-text (all context_length positions of every caption through the text tower)"}
 
+    def sample(n, mb=None):
+        step(mb)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            step(mb)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    # Two more samples on the default line, same process, outside the K timed steps:
+    #   reference_work    every row the reference executes: all context_length positions of every caption AND the full last block of both towers
+    #                     (no packed text rows, no pooled last block) -- the native kernels on exactly the reference's work
+    #   accum8_gbs32768   the metric's own global batch on ONE GPU with the reference's accumulation semantics (train.py:236-311): a no-grad feature
+    #                     pass over 8 micro-batches of 4096, then each micro-batch again with gradient against the 32768 x 32768 logits
+    reference_work = accum8 = None
+    extra_ok = (world == 1 and not args.no_extra_lines and not args.no_dense_text_line and args.model == "ViT-B-32" and not args.siglip and F_ACC == 1
+                and pipe is None and not args.grad_checkpointing and args.data_ranks == 1)
+    if extra_ok and model.pack_text:
+        try:
+            model.pack_text = False
+            model.pooled_last_block = model.visual.pooled_last_block = False
+            td = sample(3)
+            reference_work = {"value": round(B / td, 1), "unit": "pairs/s", "ms_per_step": round(td * 1e3, 2), "steps": 3,
+                              "what": "same step on exactly the rows the reference executes: --dense-text AND pooled_last_block=False (every position of every "
+                                      "caption through the text tower, the last block of both towers on every row)"}
+        except Exception as e:  # a sample must never take the bench line down with it
+            reference_work = {"error": repr(e)[:300]}
+        finally:
+            model.pack_text = True
+            model.pooled_last_block = model.visual.pooled_last_block = True
+    if extra_ok and B == 4096:
+        try:
+            mb8 = micro + [synthetic_batch(cfg, B, seed=1234 + 1000 * j, rank=rank, device=dev) for j in range(1, 8)]
+            td = sample(2, mb8)
+            accum8 = {"value": round(8 * B / td, 1), "unit": "pairs/s", "ms_per_step": round(td * 1e3, 1), "steps": 2, "global_batch": 8 * B, "accum_freq": 8,
+                      "what": "the metric's global batch 32768 on ONE GPU: --accum-freq 8 with the reference's semantics (train.py:236-311: features of the 8 "
+                              "micro-batches of 4096 under no_grad, then every micro-batch again with gradient against the 32768 x 32768 logits), one "
+                              "optimizer step per 32768 pairs; 4 forward-equivalents per pair instead of 3"}
+            del mb8
+        except Exception as e:
+            accum8 = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = B * F_ACC * world / (elapsed / args.steps)
@@ -513,6 +560,10 @@ def main():
         }
         if dense_text is not None:
             line["dense_text_tower"] = dense_text
+        if reference_work is not None:
+            line["reference_work"] = reference_work
+        if accum8 is not None:
+            line["accum8_gbs32768"] = accum8
         if not args.no_roofline:
             s = timer.summary()
             nt, tn, allg = s["nt"], s["tn"], s["all"]

@@ -26,9 +26,20 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+// OCN_DEV_BUILD (open_clip_amd/build.py --dev -> libopenclip_hip_dev.so): the developer knobs of include/openclip_hip_debug.h that reach INTO
+// the kernels -- ablation bits that drop stores / loads / arithmetic (results wrong), the per-tile timeline build, cache-policy flips -- exist only
+// in that build.  In the product library ABL() folds to 0 and none of it is compiled.
+#ifdef OCN_DEV_BUILD
+#define ABL(ARGS, BITS) ((ARGS).ablate & (BITS))
+#else
+#define ABL(ARGS, BITS) 0
+#endif
+
 namespace {
 
+#ifdef OCN_DEV_BUILD
 __device__ long long g_nt5_trace[1024];  // developer timeline (DBG kernels only): 2 workgroups x 8 tiles x 8 stamps
+#endif
 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 constexpr int UNIT = 16384;
@@ -79,8 +90,65 @@ OCN_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long row0, int rows_t
     return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + row0 * ld * esz), 0, (int)bytes, 0x00020000);
 }
 
+// What the main loop fetches ahead for the epilogue: PFN loads of 16 bytes per lane, issued three phases (~2 us) before the epilogue starts,
+// behind every DMA the remaining phases wait for (vmcnt retires in order), so the main loop never waits for them:
+//   dGELU     the saved 8-bit gelu' of the wave's WHOLE 128 x 64 sub-tile (8 KiB = 32 VGPRs): load j = rows j*16 + (lane >> 2), bytes
+//             (lane & 3)*16 .. +15 of the wave's 64 -- one 64-byte segment per row and instruction.  (Round 3 fetched them per 32 x 32 block,
+//             4 bytes per lane = 32-byte row segments, from inside the epilogue: the PMC pass showed the saved derivatives crossing the
+//             L2 -> fabric boundary 1.85 times, and the first wait of every tile sat on a full HBM round trip.)
+//   residual  the fp32 residual rows of the first two 32 x 32 blocks = slots 0 and 1 of the epilogue's operand ring
+template <int EPI>
+struct NtPf {
+    static constexpr int N = (EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32) ? 8 : 0;
+};
+
+// byte offset of this lane's 4 fp32 columns in row it*8 + (lane >> 3) of 32 x 32 block blk (fp32-staged epilogues, residual prefetch)
+OCN_DEV unsigned f32blk_off(const GemmNtArgs& a, int lane_o, int wm, int gn_w, int blk, int it, unsigned esz) {
+    const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
+    const int gn = gn_w + hb * 32 + (lane_o & 7) * 4;
+    const int row = wm * 128 + ha * 64 + s * 32 + it * 8 + (lane_o >> 3);
+    return ((unsigned)(row * a.ldc + gn) * esz) | (gn < a.N ? 0u : OOB);  // OOB: past the descriptor's bound (no select, no branch)
+}
+
+template <int EPI, int AUX>
+OCN_DEV void epi_prefetch(const GemmNtArgs& a, int m0, int n0, int wm, int wn, int lane, u32x4 (&pf)[8]) {
+    if constexpr (NtPf<EPI>::N > 0) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // see epilogue5: keeps the address arithmetic out of the tile loop's live set
+        const int m_ld = ABL(a, 128) ? 0 : a.M;
+        const int gn_w = n0 + wn * 64;
+        if constexpr (EPI == OCN_EPI_DGELU) {
+            const __amdgpu_buffer_rsrc_t r_aux = tile_rsrc(a.aux, m0, m_ld, a.ldc, 1);
+            const int gn = gn_w + (lane_o & 3) * 16;
+            const unsigned base = (unsigned)((wm * 128 + (lane_o >> 2)) * a.ldc + gn) | (gn < a.N ? 0u : OOB);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r_aux, base + (unsigned)(j * 16 * a.ldc), 0, (AUX & 8) ? 2 : 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 4);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    pf[blk * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(r_res, f32blk_off(a, lane_o, wm, gn_w, blk, it, 4u), 0, (AUX & 8) ? 2 : 0);
+        }
+    }
+}
+
+OCN_DEV void lds_w64x2(unsigned addr, u32x4 v) {  // 16 bytes as two 8-byte stores (the u8 image's rows are 8-, not 16-byte aligned)
+    const u32x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(addr), "v"(lo), "v"(hi) : "memory");
+}
+OCN_DEV void lds_r32x8(unsigned a0, unsigned (&q)[2][4]) {  // the lane's four 4-byte quads of both 32-column halves of a row of the u8 image
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:8\n\tds_read_b32 %2, %8 offset:16\n\tds_read_b32 %3, %8 offset:24\n\t"
+                 "ds_read_b32 %4, %8 offset:32\n\tds_read_b32 %5, %8 offset:40\n\tds_read_b32 %6, %8 offset:48\n\tds_read_b32 %7, %8 offset:56\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0][0]), "=&v"(q[0][1]), "=&v"(q[0][2]), "=&v"(q[0][3]), "=&v"(q[1][0]), "=&v"(q[1][1]), "=&v"(q[1][2]), "=&v"(q[1][3])
+                 : "v"(a0)
+                 : "memory");
+}
+
 template <int EPI, int AUX = 0>
-OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg,
+OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg, u32x4 (&pf)[8],
                        long long* dbg = nullptr) {
     // Lane constants are laundered through an empty asm once per tile: otherwise hipcc hoists ~40 VGPRs of epilogue
     // addresses (per-row store offsets, swizzled staging addresses) out of the tile loop and keeps them live across the
@@ -92,16 +160,17 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const int rd_row = lane_o >> 3, rd_chunk = lane_o & 7;
     const unsigned rd_addr = stg + rd_row * 128 + ((rd_chunk ^ rd_row) << 4);  // + it * 1024 for rows it*8 + rd_row
     constexpr bool IS_GELU = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);  // two-output activation epilogues
-    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || EPI == OCN_EPI_CE_GRAD);
+    constexpr bool IS_DGELU = (EPI == OCN_EPI_DGELU);
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || EPI == OCN_EPI_CE_GRAD);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
-    // developer knobs 32 / 128: zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued but the
-    // bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
-    const int m_st = (a.ablate & 32) ? 0 : a.M, m_ld = (a.ablate & 128) ? 0 : a.M;
+    // developer knobs 32 / 128 (OCN_DEV_BUILD only): zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued
+    // but the bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
+    const int m_st = ABL(a, 32) ? 0 : a.M, m_ld = ABL(a, 128) ? 0 : a.M;
     const bool aux_is_out = IS_GELU;
-    // developer knob 0x80000: every store of this workgroup lands in ONE 64 KiB window (per workgroup, at the head of the output) that
-    // stays resident in L2 -- the stores are issued and acknowledged as usual but never have to wait for HBM: what the tile loop would
-    // cost if no operand wait ever sat behind a store acknowledgement (profiles/r02_nt6_trickled_epilogue_experiment.txt, finding (a))
-    const bool win = (a.ablate & 0x80000) != 0;
+    // developer knob 0x80000 (OCN_DEV_BUILD only): every store of this workgroup lands in ONE 64 KiB window (per workgroup, at the head of the
+    // output) that stays resident in L2 -- the stores are issued and acknowledged as usual but never have to wait for HBM: what the tile loop
+    // would cost if no operand wait ever sat behind a store acknowledgement (profiles/r02_nt6_trickled_epilogue_experiment.txt, finding (a))
+    const bool win = ABL(a, 0x80000) != 0;
     const unsigned omask = win ? 0xfff0u : ~0u;
     const long m_win = win ? (long)((blockIdx.x * 65536L) / ((long)a.ldc * (OUT_F32 ? 4 : 2))) : m0;
     const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m_win, m_st, a.ldc, OUT_F32 ? 4 : 2);
@@ -110,14 +179,15 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
     // Bias is fetched ONCE, before any store of this tile is issued (a later load would have to wait behind the stores):
     // bf16-staged epilogues add it in the accumulator layout (before rounding), fp32-staged ones after the transpose.
+    // (The dGELU epilogue has none: ocn_launch_nt5 hands a dGELU GEMM with a bias to the general kernel.)
     f32x4 bv[2][4], bq[2];
-    if (BF16_STAGED) {
+    if (BF16_STAGED && !IS_DGELU) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 bv[hb][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + 8 * g + 4 * lh) * 4, 0, 0));
-    } else {
+    } else if (!BF16_STAGED) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
             bq[hb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + rd_chunk * 4) * 4, 0, 0));
@@ -187,7 +257,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     }
     // Every DMA issued so far must have landed: the first phases of the next tile then need no vmcnt wait and the
     // stores below drain under them.  (hipcc does not know about the asm LDS-DMAs; its own loads / stores below get
-    // ordinary counted waits.)
+    // ordinary counted waits.)  This is also where the operands the main loop fetched ahead (pf) are waited for.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dbg) dbg[5] = wall_clock64();
     const int row_w = wm * 128;  // this wave's first row inside the tile
@@ -195,25 +265,33 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         const int gn = gn_w + rd_chunk * 8;
         const unsigned col_off = gn < a.N ? (unsigned)gn * 2u : OOB;
         const unsigned col_off_aux = gn < a.N ? (unsigned)gn : OOB;  // the saved derivative: one byte per element
-        // u8 staging image of a 32 x 64 sub-block: rows of 64 bytes padded to 72 (a lane writes the 4 bytes of its register quad, reads 8)
+        // u8 staging image of a 32 x 64 sub-block: rows of 64 bytes padded to 72.  GELU: a lane writes the 4 bytes of its register quad and reads 8 bytes
+        // of a row; dGELU the other way round: a lane writes the 16 bytes it loaded and reads its four quads of both 32-column halves
         const unsigned aw_addr = stg + lr * 72 + lh * 4, ar_addr = stg + rd_row * 72 + rd_chunk * 8;
+        const unsigned dw_addr = stg + (lane_o >> 2) * 72 + (lane_o & 3) * 16;
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // GELU: gelu(v) AND gelu'(v) come out of one evaluation of the shared erf / exp parts; the derivative is what
-                // is saved for the backward (aux, 8-bit fixed point), whose epilogue is then a plain multiply (EPI_DGELU below)
+                // is saved for the backward (aux, 8-bit fixed point), whose epilogue is then a plain multiply (dGELU)
                 bf16x4 pk[2][4];
                 unsigned dq[2][4];
+                if constexpr (IS_DGELU) {
+                    lds_w64x2(dw_addr, pf[(ha * 2 + s) * 2]);
+                    lds_w64x2(dw_addr + 16 * 72, pf[(ha * 2 + s) * 2 + 1]);
+                    lds_r32x8(aw_addr, dq);
+                }
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
-                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else if (EPI != OCN_EPI_CE_GRAD) v = v + bv[hb][g];
+                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else if (IS_GELU) v = v + bv[hb][g];
+                        if (IS_DGELU) v = v * dgelu_unpack4(dq[hb][g]);  // gelu'(pre-activation), saved by the forward epilogue
                         if (IS_GELU) {
                             f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
-                            if (!(a.ablate & 1)) {
+                            if (!ABL(a, 1)) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     float g1, d1;
@@ -259,40 +337,23 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                 }
             }
     } else {
-        // 32x32 fp32 blocks (128-byte rows).  The epilogue operand of block k+1 (residual rows / saved pre-activation)
-        // is fetched BEFORE block k's stores are issued, so waiting for it never drains the stores.
-        constexpr bool HAS_EX = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_DGELU);
-        unsigned colmask[2];  // OR-ed into byte offsets: pushes out-of-range columns past the descriptor's bound (no select, no branch)
+        // 32x32 fp32 blocks (128-byte rows).  The residual rows of block k + DEPTH - 1 are requested before block k's stores are issued: vmcnt
+        // retires loads AND stores in issue order, so waiting for a block's operand also waits for every store issued before its request -- with a
+        // ring of four that is never the store of the block just before.  Slots 0 and 1 arrive with the main loop's prefetch (pf).
+        constexpr bool HAS_EX = (EPI == OCN_EPI_BIAS_RESID_F32);
+        constexpr int DEPTH = HAS_EX ? 4 : 1;
+        f32x4 ex[DEPTH][4];
+        auto load_ex = [&](int blk, f32x4 (&e)[4]) {
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) colmask[hb] = (gn_w + hb * 32 + rd_chunk * 4) < a.N ? 0u : OOB;
-        auto byte_off = [&](int blk, int it, unsigned esz) -> unsigned {  // this lane's 4 columns, row it*8+rd_row of block blk
-            const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
-            const int gn = gn_w + hb * 32 + rd_chunk * 4;
-            const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
-            return ((unsigned)(row * a.ldc + gn) * esz) | colmask[hb];
-        };
-        // Epilogue operands (residual rows / saved gelu') sit in a ring of DEPTH blocks: block k + DEPTH - 1 is requested before the
-        // stores of block k are issued.  vmcnt retires loads AND stores in issue order, so waiting for block k's operand also waits
-        // for every store issued before its request: with DEPTH = 2 that is the stores of block k - 2, whose HBM acknowledgement is
-        // what the epilogue then idles on.  AUX bit 5 (32) deepens the ring: the dGELU epilogue (4 bytes per lane and row: the saved
-        // derivatives are 8-bit) requests ALL eight blocks before its first store (32 VGPRs, no wait ever sits behind a store), the
-        // fp32 residual (16 bytes) runs four blocks ahead (64 VGPRs).
-        constexpr int DEPTH = !HAS_EX ? 1 : ((AUX & 32) ? (EPI == OCN_EPI_DGELU ? 8 : 4) : 2);
-        typedef typename std::conditional<EPI == OCN_EPI_DGELU, unsigned, f32x4>::type ex_t;  // dGELU: 4 saved derivatives in 8 bits each
-        ex_t ex[DEPTH][4];
-        auto load_ex = [&](int blk, ex_t (&e)[4]) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    e[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, byte_off(blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
-                } else if constexpr (EPI == OCN_EPI_DGELU) {
-                    e[it] = __builtin_amdgcn_raw_buffer_load_b32(r_aux, byte_off(blk, it, 1u), 0, (AUX & 8) ? 2 : 0);
-                }
-            }
+            for (int it = 0; it < 4; ++it)
+                e[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, f32blk_off(a, lane_o, wm, gn_w, blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
         };
         if constexpr (HAS_EX) {
 #pragma unroll
-            for (int b = 0; b < DEPTH - 1; ++b) load_ex(b, ex[b]);
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) ex[b][it] = __builtin_bit_cast(f32x4, pf[b * 4 + it]);
+            load_ex(2, ex[2]);
         }
 #pragma unroll
         for (int blk = 0; blk < 8; ++blk) {
@@ -311,14 +372,11 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
+                const unsigned off = f32blk_off(a, lane_o, wm, gn_w, blk, it, 4u) & omask;
                 if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[blk % DEPTH][it]), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
-                } else if constexpr (EPI == OCN_EPI_DGELU) {
-                    const f32x4 p4 = dgelu_unpack4(ex[blk % DEPTH][it]);  // gelu'(pre-activation), saved by the forward epilogue
-                    const bf16x4 o4 = {f2bf(v[0] * p4[0]), f2bf(v[1] * p4[1]), f2bf(v[2] * p4[2]), f2bf(v[3] * p4[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), r_out, byte_off(blk, it, 2u) & omask, 0, AUX & 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[blk % DEPTH][it]), r_out, off, 0, AUX & 2);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, byte_off(blk, it, 4u) & omask, 0, AUX & 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, off, 0, AUX & 2);
                 }
             }
         }
@@ -473,6 +531,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     DMA_A0(0, 1) DMA_A0(1, 1) DMA_B0(0, 1) DMA_B0(1, 1) DMA_B1(0, 1) DMA_B1(1, 1)
     adv_ab();
 
+    constexpr int PFN = NtPf<EPI>::N;
+    u32x4 pf[8];          // epilogue operands fetched ahead by the main loop (epi_prefetch; unused when PFN == 0)
     f32x16 acc[2][2][2];  // [A half][32-row sub-block][B half], each a 32x32 C^T tile
     bf16x8 fa[2][2];      // A fragments: [buffer][sub-block]
     bf16x8 fb[2][4];      // B fragments of the whole K-tile: [B half][k-substep]
@@ -502,10 +562,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 
     // one K-tile held in ring parity P; SKIP: the epilogue (or prologue) before it already drained every DMA
     // (Measured, no effect: issuing the DMA pieces of the two waves that share a SIMD in different k-substeps.)
-#define KTILE(P, SKIP, LAST)                                                                          \
+    // PFM (epilogues with a prefetch, PFN > 0): 1 = the tile's second-to-last K-tile: the PFN epilogue-operand loads are issued behind its two
+    // A1 pieces; from there on every counted wait carries + PFN (the loads sit between the DMAs in the in-order vmcnt queue and are never
+    // waited for); 2 = the tile's last K-tile: its odd phase needs nothing that is still in flight (its A1 unit was published by the even
+    // phase) -- the wait that used to publish the NEXT tile's first K-tile would now wait for the prefetch, so that publication moves to a
+    // barrier behind the epilogue's own vmcnt(0).
+#define KTILE(P, SKIP, LAST, PFM)                                                                 \
     {                                                                                             \
         /* ---- even phase: A0 x (B0, B1) ---- */                                                 \
-        if (!(SKIP)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+        if (!(SKIP)) {                                                                            \
+            if ((PFM) == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + PFN) : "memory");         \
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                 \
+        }                                                                                         \
         __builtin_amdgcn_s_barrier();                                                             \
         SB();                                                                                     \
         RD_A(fa[1], 1, 0, P) RD_B(1, P)                                                           \
@@ -518,6 +586,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         acc[0][1][1] = mfma32(fb[1][0], fa[0][1], acc[0][1][1]);                                  \
         PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 2, 0, P) RD_B(2, P)                                                           \
+        if ((PFM) == 1) epi_prefetch<EPI, AUX>(a, pm0, pn0, wm, wn, lane, pf);                    \
         SB(); PRIO_ON()                                                                                     \
         MM(0, fa[1], 1)                                                                           \
         PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
@@ -531,7 +600,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         MM(0, fa[1], 3)                                                                           \
         PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         /* ---- odd phase: A1 x (B0, B1), B fragments from registers ---- */                      \
-        if (!(SKIP)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                             \
+        if ((PFM) == 1) { if (!(SKIP)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + PFN) : "memory"); } \
+        else if ((PFM) == 0 || PFN == 0) { if (!(SKIP)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } \
         __builtin_amdgcn_s_barrier();                                                             \
         SB();                                                                                     \
         RD_A(fa[1], 1, 1, P)                                                                      \
@@ -568,7 +638,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 
     const unsigned stg = lds_base + RING_BYTES + wave * STG_BYTES;
     long long* dbg = nullptr;
+#ifdef OCN_DEV_BUILD
     if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = g_nt5_trace + (blockIdx.x ? 512 : 0);
+#endif
 #define STAMP(IDX) if (DBG && dbg && i < 8) dbg[i * 8 + (IDX)] = wall_clock64();
 #if (OCN_PRIO_MODE & 2)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -588,16 +660,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         RD_A(fa[0], 0, 0, 0) RD_B(0, 0)
         LGKM0();
         SB();
-        for (int kt = 0; kt < nk; kt += 2) {
+        int pm0, pn0;
+        tile_origin(i, pm0, pn0);
+        for (int kt = 0; kt + 2 < nk; kt += 2) {
             const bool skip = (kt == 0);
-            KTILE(0, skip, false)
-            KTILE(1, false, kt + 2 >= nk)
+            KTILE(0, skip, false, 0)
+            KTILE(1, false, false, 0)
+        }
+        {  // the tile's last two K-tiles (peeled: the epilogue-operand prefetch and its wait counts are compile-time)
+            const bool skip = (nk == 2);
+            KTILE(0, skip, false, 1)
+            KTILE(1, false, true, 2)
         }
         STAMP(3)
-        int m0, n0;
-        tile_origin(i, m0, n0);
-        epilogue5<EPI, AUX>(a, acc, m0, n0, wm, wn, lane, stg, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
-        if (a.ablate & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // developer knob: let the tile's stores drain before the next main loop
+        epilogue5<EPI, AUX>(a, acc, pm0, pn0, wm, wn, lane, stg, pf, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
+        if (ABL(a, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // developer knob: let the tile's stores drain before the next main loop
+        if constexpr (PFN > 0) __builtin_amdgcn_s_barrier();  // publishes the next tile's first K-tile (see KTILE, PFM = 2)
         STAMP(4)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released
@@ -614,9 +692,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 }
 
 int g_num_cu = 0;
-#ifndef OCN_NT5_DEEP_RING
-#define OCN_NT5_DEEP_RING true  // shipped default of AUX bit 5 (A/B: tools/ab_deep_ring.py, profiles/r02_deep_operand_ring.txt)
-#endif
 }  // namespace
 extern int g_ocn_tuning[16];
 namespace {
@@ -654,6 +729,18 @@ int nt5_stagger(int ntiles, int K, int forced) {
     return tile_us * 100 / 4;
 }
 
+template <int EPI, int AUXV>
+int launch5_aux(const GemmNtArgs& a, int grid, hipStream_t st) {
+    static bool set_ = false;
+    if (!set_) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, AUXV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        set_ = true;
+    }
+    hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, AUXV>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+    OCN_CHECK_LAUNCH("ocn_gemm_nt");
+    return OCN_OK;
+}
+
 template <int EPI>
 int launch5(GemmNtArgs a, hipStream_t st) {
     if (g_num_cu == 0) {
@@ -662,6 +749,9 @@ int launch5(GemmNtArgs a, hipStream_t st) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         g_num_cu = n;
     }
+#ifndef OCN_DEV_BUILD
+    a.ablate = 0;
+#endif
     a.tiles_n = ocn_cdiv(a.N, 256);
     a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
     a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
@@ -675,7 +765,17 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     // more than collectives that are active for ~1.5 % of a step can take back -- so k = 1 stays the default.
     const int per_cu = g_ocn_tuning[10] > 0 ? g_ocn_tuning[10] : 1;
     const int grid = a.ntiles < g_num_cu * per_cu ? a.ntiles : g_num_cu * per_cu;
-    if (a.ablate & 64) {  // developer build: per-tile timeline into a side buffer passed in a.resid/a.aux (tools/gemm_trace.py)
+    // Cache policy of the epilogue (template parameter AUX: bit 1 (2) = non-temporal stores, bit 3 (8) = non-temporal loads of the
+    // residual / saved derivative; profiles/r01_nt5_cache_policy_sweep.txt, profiles/r04_nt5_epilogue_prefetch.txt):
+    //   stores: non-temporal for the two-output GELU epilogue (256 KiB per tile that nothing re-reads before they are long evicted:
+    //           streamed past the L2 they stop displacing the operand panels, +5..8 %) and for wide bf16 outputs (N >= 1024: the QKV
+    //           projections +4..6 %, the dGELU output);
+    //   loads:  non-temporal for the fp32 residual and the saved gelu' -- both read exactly once.
+    constexpr bool is_gelu = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);
+    const bool st_nt = is_gelu || ((EPI == OCN_EPI_BF16 || EPI == OCN_EPI_DGELU) && a.N >= 1024);
+    const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_DGELU);
+#ifdef OCN_DEV_BUILD
+    if (a.ablate & 64) {  // per-tile timeline into g_nt5_trace (tools/gemm_trace.py)
         static bool dbg_attr_set = false;
         if (!dbg_attr_set) {
             (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -685,60 +785,44 @@ int launch5(GemmNtArgs a, hipStream_t st) {
         OCN_CHECK_LAUNCH("ocn_gemm_nt");
         return OCN_OK;
     }
-    // Cache policy of the epilogue's stores: the two-output GELU epilogue writes 256 KiB per tile that nothing re-reads before
-    // they are long evicted -- streamed past the L2 (non-temporal) they stop displacing the operand panels: +5..8 % on that
-    // kernel, -2 % on the dGELU / residual ones (profiles/r01_nt5_cache_policy_sweep.txt).  Developer knob bits 2 / 8 flip the
-    // store / load choice.
-    //   stores: non-temporal for the GELU epilogue and for wide bf16 outputs (N >= 1024: the QKV projections, +4..6 %);
-    //   loads:  non-temporal for the fp32 residual, which is read exactly once (+1..3 %); the saved GELU derivative of the dGELU
-    //           epilogue is better left cacheable (-5 % otherwise).
-    const bool st_nt = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU) || (EPI == OCN_EPI_BF16 && a.N >= 1024);
-    const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32);
-    // bit 5 (32): deep operand ring of the dGELU / fp32-residual epilogues (see epilogue5); developer knob 0x100000 flips it
-    constexpr bool has_ex = (EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32);
-    const bool deep = has_ex && (OCN_NT5_DEEP_RING != ((a.ablate & 0x100000) != 0));
-    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0) | ((a.ablate & 16) ? 16 : 0) | (deep ? 32 : 0);
-#define OCN_NT5_LAUNCH_AUX(AUXV)                                                                                                   \
-    if (aux == (AUXV)) {                                                                                                           \
-        static bool set_ = false;                                                                                                  \
-        if (!set_) {                                                                                                               \
-            (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, AUXV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
-            set_ = true;                                                                                                           \
-        }                                                                                                                          \
-        hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, AUXV>), dim3(grid), dim3(512), LDS_BYTES, st, a);                           \
-        OCN_CHECK_LAUNCH("ocn_gemm_nt");                                                                                           \
-        return OCN_OK;                                                                                                             \
+    // developer knob bits 2 / 8 flip the store / load policy, bit 16 fetches the A operand non-temporally
+    const int aux = ((st_nt != ((a.ablate & 2) != 0)) ? 2 : 0) | ((ld_nt != ((a.ablate & 8) != 0)) ? 8 : 0) | ((a.ablate & 16) ? 16 : 0);
+    switch (aux) {
+        case 0: return launch5_aux<EPI, 0>(a, grid, st);
+        case 2: return launch5_aux<EPI, 2>(a, grid, st);
+        case 8: return launch5_aux<EPI, 8>(a, grid, st);
+        case 10: return launch5_aux<EPI, 10>(a, grid, st);
+        case 16: return launch5_aux<EPI, 16>(a, grid, st);
+        case 18: return launch5_aux<EPI, 18>(a, grid, st);
+        case 24: return launch5_aux<EPI, 24>(a, grid, st);
+        default: return launch5_aux<EPI, 26>(a, grid, st);
     }
-    OCN_NT5_LAUNCH_AUX(2)
-    OCN_NT5_LAUNCH_AUX(8)
-    OCN_NT5_LAUNCH_AUX(10)
-    OCN_NT5_LAUNCH_AUX(16)
-    OCN_NT5_LAUNCH_AUX(18)
-    OCN_NT5_LAUNCH_AUX(24)
-    if constexpr (has_ex) {
-        OCN_NT5_LAUNCH_AUX(32)
-        OCN_NT5_LAUNCH_AUX(40)
-    }
-#undef OCN_NT5_LAUNCH_AUX
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false>), dim3(grid), dim3(512), LDS_BYTES, st, a);
-    OCN_CHECK_LAUNCH("ocn_gemm_nt");
-    return OCN_OK;
+#else
+    // the product library holds exactly the instantiations the rules above select
+    if constexpr (is_gelu) return launch5_aux<EPI, 2>(a, grid, st);
+    else if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) return launch5_aux<EPI, 8>(a, grid, st);
+    else if constexpr (EPI == OCN_EPI_DGELU) return st_nt ? launch5_aux<EPI, 10>(a, grid, st) : launch5_aux<EPI, 8>(a, grid, st);
+    else if constexpr (EPI == OCN_EPI_BF16) return st_nt ? launch5_aux<EPI, 2>(a, grid, st) : launch5_aux<EPI, 0>(a, grid, st);
+    else return launch5_aux<EPI, 0>(a, grid, st);
+#endif
 }
 
 }  // namespace
 
 extern "C" int ocn_debug_nt5_trace(long long* host_out /*[1024]*/) {
+#ifdef OCN_DEV_BUILD
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt5_trace), sizeof(long long) * 1024) == hipSuccess ? OCN_OK : OCN_ERR_LAUNCH;
+#else
+    (void)host_out;
+    ocn_set_error("ocn_debug_nt5_trace: the per-tile timeline exists only in the developer build (open_clip_amd/build.py --dev)");
+    return OCN_ERR_INVALID;
+#endif
 }
 
 int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
     // needs whole 128-k pairs of K-tiles, 16-byte aligned bf16 rows on the output side and vector-width columns
     if (a.K % 128 != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 1;
+    if (epilogue == OCN_EPI_DGELU && a.bias) return 1;  // the persistent kernel's dGELU epilogue carries no bias (no caller has one)
     if ((long)a.ldc * 4 * 256 >= 0x7fffffffL) return 1;  // 32-bit buffer offsets inside a tile
     switch (epilogue) {
         case OCN_EPI_BF16: return launch5<OCN_EPI_BF16>(a, st);

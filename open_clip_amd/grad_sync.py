@@ -72,8 +72,14 @@ def flat_ranges(tensors):
 
 
 class NativeGradSync:
-    def __init__(self, model, world_size: int, comm=None, process_group=None, broadcast_parameters: bool = True):
+    def __init__(self, model, world_size: int, comm=None, process_group=None, broadcast_parameters: bool = True, find_unused_parameters: bool = False):
+        """``find_unused_parameters`` (DDP's flag of the same name): a trainable parameter may receive no gradient on some or all ranks.  Every
+        reduction then waits for ``finish()``, which first all-reduces a per-parameter "has a gradient" bitmap so that all ranks reduce the same
+        tensors in the same order (a parameter used nowhere keeps ``grad is None``, one used on some ranks takes part with zeros elsewhere) -- no
+        overlap with the backward.  Without it (default) every registered parameter MUST receive a gradient in every synchronised backward:
+        ``finish()`` raises otherwise, naming the parameters, instead of letting ranks issue different collectives (a silent RCCL hang)."""
         self.model, self.world_size, self.comm, self.pg = model, int(world_size), comm, process_group
+        self.find_unused = bool(find_unused_parameters)
         self.enabled = True
         self.stats = {"collectives": 0, "elements": 0, "ranges_per_group": []}
         self._stream = None
@@ -86,6 +92,7 @@ class NativeGradSync:
             self._of[p] = key
         self._pending = {}
         self._fired = {}
+        self._reduced_by_hook = {}
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self._of]
         if broadcast_parameters and self.world_size > 1:
             self.broadcast_parameters()
@@ -102,6 +109,15 @@ class NativeGradSync:
             flat.mul_(1.0 / self.world_size)
         self.stats["collectives"] += 1
         self.stats["elements"] += flat.numel()
+
+    def _allreduce_sum_small(self, t):
+        if self.world_size == 1 and self.comm is None:
+            return
+        if self.comm is not None:
+            self.comm.all_reduce_sum(t)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def broadcast_parameters(self):
         """every rank starts from rank 0's parameters and buffers (DDP does this at construction, base_task.py:227)"""
@@ -132,7 +148,7 @@ class NativeGradSync:
         dev = grads[0].device
         cs = self._comm_stream(dev)
         ranges = flat_ranges(grads)
-        self.stats["ranges_per_group"].append(len(ranges))
+        self.stats["ranges_per_group"] = (self.stats["ranges_per_group"] + [len(ranges)])[-64:]  # bounded: the last step's groups
         if cs is None:
             for flat, _ in ranges:
                 self._allreduce_mean(flat)
@@ -154,8 +170,9 @@ class NativeGradSync:
         key = self._of[p]
         fired = self._fired.setdefault(key, [])
         fired.append(p)
-        if key != "scalars" and len(fired) == len(self._groups[key]):
+        if key != "scalars" and not self.find_unused and len(fired) == len(self._groups[key]):
             self._fired[key] = []
+            self._reduced_by_hook[key] = True
             self._reduce([q.grad for q in self._groups[key]])  # registration order: the same on every rank
 
     @contextmanager
@@ -170,11 +187,31 @@ class NativeGradSync:
     def finish(self):
         """reduce what the hooks have not (0-d parameters packed into one tensor; incomplete groups), then order the current stream
         behind the communication stream.  Call once per optimizer step, after the last backward."""
+        names = None
         left = []
-        for key in self._groups:  # registration order, not hook order
-            fired = self._fired.get(key) or []
-            left += [q for q in self._groups[key] if q.grad is not None and any(q is f for f in fired)]
-            self._fired[key] = []
+        if self.find_unused:
+            # one bitmap over ALL registered parameters (same length and order on every rank), summed: who has a gradient anywhere
+            allp = [q for key in self._groups for q in self._groups[key]]
+            have = torch.tensor([0.0 if q.grad is None else 1.0 for q in allp], device=allp[0].device)
+            self._allreduce_sum_small(have)
+            for q, n in zip(allp, have.tolist()):
+                if n > 0:
+                    if q.grad is None:
+                        q.grad = torch.zeros_like(q)
+                    left.append(q)
+        else:
+            for key in self._groups:  # registration order, not hook order
+                if self._reduced_by_hook.get(key):
+                    continue
+                missing = [q for q in self._groups[key] if q.grad is None]
+                if missing:  # the other ranks may have reduced this group already: fail loudly, here, instead of hanging in RCCL
+                    names = names or {id(p): n for n, p in self.model.named_parameters()}
+                    raise RuntimeError("NativeGradSync: no gradient reached " + ", ".join(names.get(id(q), "?") for q in missing[:8]) + " on this rank; "
+                                       "every trainable parameter must take part in every synchronised backward (freeze it before construction, or "
+                                       "construct NativeGradSync(find_unused_parameters=True), which reduces in finish() behind a has-gradient bitmap)")
+                left += self._groups[key]
+        self._fired = {}
+        self._reduced_by_hook = {}
         scalars = [q for q in left if q.dim() == 0]
         rest = [q.grad for q in left if q.dim() > 0]
         if rest:

@@ -13,7 +13,8 @@ output of the transform) re-designed for the native path:
     pipe.submit(u8_host, text_host)              # enqueue the copy of batch i+1 (returns immediately)
     batch = pipe.next()                          # device tensors of batch i, ordered after their copy on the current stream
     out = model(**batch)                         # NativeCLIP accepts the uint8 image directly
-    pipe.release(batch)                          # after the forward has consumed the pixels (records the slot's 'free' event)
+    pipe.release(batch)                          # any time after the forward is enqueued (records the slot's 'free' event): the backward
+                                                 # reads nothing of the slot -- next() hands out per-step copies of the tokens / text layout
 
 ``prepare_batch`` keeps working on the result: it leaves integer tensors (uint8 pixels, int64 tokens) untouched.
 PyTorch is plumbing here (pinned allocations, streams, events); there is no arithmetic in this file."""
@@ -144,14 +145,18 @@ class DeviceBatchPipeline:
         torch.cuda.current_stream(self.device).wait_event(s["ready"])
         self._r = (self._r + 1) % self.depth
         self._queued -= 1
-        text = s["text"]
+        # What the BACKWARD reads again -- the token ids (embedding backward) and, with a host plan, the whole addressing layout of the packed text
+        # tower (seq_off / order / last_row / posidx / packed ids: varlen attention backward, embedding backward, every recomputed block under grad
+        # checkpointing) -- is copied out of the slot here, on the compute stream, into tensors of this step (a few MB): the slot then holds nothing
+        # that outlives the forward, and ``release()`` right after the forward can never let the copy stream overwrite addressing data under a
+        # running backward.  Only the pixels are read in place (by the patch kernel, forward only).
+        text = s["text"].clone()
         if s["plan"] is not None:  # rides on the tensor object (prepare_batch leaves a device int64 tensor as it is): model._TextPack picks it up
-            text = s["text"].view(s["text"].shape)
-            text._ocn_host_plan = s["plan"].device_views(s["plan_ints"], s["plan_tokens"])
+            plan = s["plan"]
+            text._ocn_host_plan = plan.device_views(s["plan_ints"][:plan.ints.numel()].clone(), s["plan_tokens"][:plan.M].clone())
         return {"image": s["image"], "text": text, "_slot": s}
 
     def release(self, batch):
-        """call once the kernels that read ``batch`` have been enqueued (after the forward; the image is only read by the patch
-        kernel, the tokens by the embedding / argmax kernels and again by the embedding backward -- release after backward when
-        the text tower trains)"""
+        """call once the forward that reads ``batch`` has been enqueued: the slot's pixels are read by the patch kernel only, and everything
+        the backward reads again (token ids, the packed text layout) was copied out of the slot by ``next()``"""
         batch["_slot"]["free"].record(torch.cuda.current_stream(self.device))

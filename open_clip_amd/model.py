@@ -877,12 +877,13 @@ class NativeCLIP(nn.Module):
     def activation_bytes_per_block(self, batch_size: int, text_rows=None):
         """(image, text) bytes one residual block saves for the backward when it is NOT recomputed: per row of width C the fp32 block
         output (4C), ln_1 / ln_2 outputs (2C + 2C), qkv (6C), the attention output (2C), the fp32 middle of the residual stream (4C), the
-        8-bit gelu' (4C) and the MLP activation (8C) = 32 C, + the attention row statistics.  A recomputed block keeps its 4C input only.
+        8-bit gelu' and the MLP activation (1 + 2 bytes per element of the block's REAL MLP width: 12 C at mlp_ratio 4, 26 C for ViT-e-14) = 20 C +
+        3 * mlp_width, + the attention row statistics.  A recomputed block keeps its 4C input only.
         ``text_rows``: rows of the packed text batch (default: every one of ``context_length`` positions)."""
         v, t = self.visual, self.transformer
         rows_v = batch_size * (v.grid_size[0] * v.grid_size[1] + 1)
         rows_t = batch_size * self.context_length if text_rows is None else int(text_rows)
-        per = lambda rows, tr: rows * (32 * tr.width + 4 * tr.resblocks[0].n_head + 8)
+        per = lambda rows, tr: rows * (20 * tr.width + 3 * tr.resblocks[0].mlp.c_fc.out_features + 4 * tr.resblocks[0].n_head + 8)
         return per(rows_v, v.transformer), per(rows_t, t)
 
     def plan_grad_checkpointing(self, batch_size: int, budget_bytes: int, text_rows=None):

@@ -191,6 +191,57 @@ def test_vitb32_step_at_batch_512_against_cpu_oracle():
     for frac, rel, k in worst[:8]:
         _report(f"oracle[ViT-B-32,B{B}]:   grad rel_l2={rel:.3e} ({frac:.2f} of its tolerance) {k}")
     assert worst[0][0] <= 1.0, worst[0]
+    # ---- the chunked fp32 GPU reference (oracle/gpu_fp32.py) is PINNED here, against the same CPU-oracle outputs: it is what stands in for
+    # the oracle at the bench's own batch (next test), where the host would need the better part of an hour
+    from oracle import gpu_fp32
+    del model, out, loss
+    torch.cuda.empty_cache()
+    g_outs, g_grads = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=128)  # 4 chunks: the chunking identity is exercised
+    pi = float((g_outs["image_features"].cpu() - outs["image_features"]).abs().max())
+    pt = float((g_outs["text_features"].cpu() - outs["text_features"]).abs().max())
+    pl = abs(float(g_outs["loss"]) - float(outs["loss"]))
+    pg = max((float((g_grads[k].cpu() - grads[k]).norm() / grads[k].norm().clamp_min(1e-30)), k) for k in grads)
+    _report(f"fp32 GPU reference vs CPU oracle [ViT-B-32,B{B}]: feat max_abs {pi:.2e}/{pt:.2e} loss |d| {pl:.2e} worst grad rel_l2 {pg[0]:.2e} ({pg[1]})")
+    assert set(g_grads) == set(grads)
+    assert pi <= 1e-5 and pt <= 1e-5 and pl <= 1e-5 and pg[0] <= 1e-4, (pi, pt, pl, pg)
+
+
+def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference():
+    """the WHOLE step at the bench's own batch (ViT-B-32, 4096 pairs: the launches bench.py times -- 204 800 image rows, the
+    packed text rows, the persistent GEMMs' full tile walks, 49 152-workgroup attention launches, the fused 4096 x 4096 logits + cross-entropy)
+    against the chunked fp32 GPU reference, which the previous test pins to the CPU oracle at batch 512: features, loss and ALL 302 gradients
+    inside the tolerances every other end-to-end test uses (tests/test_model_gpu.py).  The 1-D gradients (biases, LayerNorm affine) are column
+    sums over M rows of bf16-rounded values and were the tensors nearest their bound at batch 512 (0.86 of it)."""
+    from oracle import gpu_fp32
+    from tests.test_model_gpu import FEAT_TOL, LOSS_TOL, _build, _grad_tol, _step
+    cfg = get_model_config("ViT-B-32")
+    B = 4096
+    state = init_state_dict(cfg, seed=0, perturb=True)
+    batch = synthetic_batch(cfg, B, seed=1234)  # the bench's own batch
+    outs, grads = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=512)
+    outs = {k: v.cpu() for k, v in outs.items()}
+    grads = {k: v.cpu() for k, v in grads.items()}
+    torch.cuda.empty_cache()
+    model = _build(cfg, state)
+    out, loss = _step(model, batch)
+    fi = float((out["image_features"].float().cpu() - outs["image_features"]).abs().max())
+    ft = float((out["text_features"].float().cpu() - outs["text_features"]).abs().max())
+    _report(f"fp32-GPU-reference[ViT-B-32,B{B}]: feat max_abs {fi:.3e}/{ft:.3e} loss {float(loss):.6f} vs {float(outs['loss']):.6f}")
+    assert fi <= FEAT_TOL and ft <= FEAT_TOL
+    assert abs(float(loss) - float(outs["loss"])) <= LOSS_TOL
+    gmax = max(float(v.norm()) for v in grads.values())
+    worst = []
+    for k, p in model.named_parameters():
+        ref = grads[k]
+        rel = float((p.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        worst.append((rel / _grad_tol(float(ref.norm()), gmax, ref.ndim), rel, k))
+    worst.sort(reverse=True)
+    for frac, rel, k in worst[:12]:
+        _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   grad rel_l2={rel:.3e} ({frac:.2f} of its tolerance) {k}")
+    one_d = sorted((rel, k) for _, rel, k in worst if grads[k].ndim <= 1)
+    _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   1-D gradients: median rel_l2 {one_d[len(one_d) // 2][0]:.3e}, worst {one_d[-1][0]:.3e} ({one_d[-1][1]}); "
+            f"matrices: worst {max(rel for _, rel, k in worst if grads[k].ndim >= 2):.3e}")
+    assert len(worst) == 302 and worst[0][0] <= 1.0, worst[0]
 
 
 def test_eval_and_inference_mode_calls(dev):

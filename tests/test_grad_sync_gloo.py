@@ -43,11 +43,12 @@ class _Block(nn.Module):
 
 
 class _Toy(nn.Module):
-    def __init__(self, d=6):
+    def __init__(self, d=6, with_unused=False):
         super().__init__()
         self.visual = nn.Module()
         self.visual.proj = nn.Parameter(torch.randn(d, d) * 0.3)
-        self.visual.unused = nn.Parameter(torch.randn(3))  # never receives a gradient
+        if with_unused:
+            self.visual.unused = nn.Parameter(torch.randn(3))  # never receives a gradient
         self.resblocks = nn.ModuleList([_Block(d, True), _Block(d, False), _Block(d, True)])
         self.logit_scale = nn.Parameter(torch.tensor(1.5))
 
@@ -68,7 +69,7 @@ def _worker(rank, world, port, q):
     b.load_state_dict(a.state_dict())
     g = torch.Generator().manual_seed(7 + rank)
     xs = [torch.randn(5, 6, generator=g) for _ in range(3)]
-    ddp = nn.parallel.DistributedDataParallel(a, find_unused_parameters=True)
+    ddp = nn.parallel.DistributedDataParallel(a)
     sync = NativeGradSync(b, world, process_group=dist.new_group())  # its own group: DDP keeps asynchronous collectives in flight on the default one
     same_start = all(torch.equal(p, q_) for p, q_ in zip(a.parameters(), b.parameters()))
     # step 1: plain; step 2: two accumulated micro-batches (no_sync on the first)
@@ -76,7 +77,6 @@ def _worker(rank, world, port, q):
     b(xs[0]).backward()
     sync.finish()
     g1 = [(n, p.grad.numpy().copy(), dict(b.named_parameters())[n].grad.numpy().copy()) for n, p in a.named_parameters() if p.grad is not None]
-    unused_ok = b.visual.unused.grad is None
     ddp.zero_grad(set_to_none=True)
     b.zero_grad(set_to_none=True)
     with ddp.no_sync():
@@ -87,6 +87,30 @@ def _worker(rank, world, port, q):
     b(xs[2]).backward()
     sync.finish()
     g2 = [(n, p.grad.numpy().copy(), dict(b.named_parameters())[n].grad.numpy().copy()) for n, p in a.named_parameters() if p.grad is not None]
+    # a trainable parameter that never receives a gradient: find_unused_parameters=True on both sides leaves it None and reduces the rest
+    # (behind a has-gradient bitmap, in finish()); the strict default raises instead of letting the ranks' collectives diverge
+    sync.remove()
+    torch.manual_seed(300 + rank)
+    c, d = _Toy(with_unused=True), _Toy(with_unused=True)
+    d.load_state_dict(c.state_dict())
+    ddp_u = nn.parallel.DistributedDataParallel(c, find_unused_parameters=True)
+    sync_u = NativeGradSync(d, world, process_group=dist.new_group(), find_unused_parameters=True)
+    ddp_u(xs[0]).backward()
+    d(xs[0]).backward()
+    sync_u.finish()
+    unused_ok = d.visual.unused.grad is None and c.visual.unused.grad is None
+    for (n, p), (_, q_) in zip(c.named_parameters(), d.named_parameters()):
+        if p.grad is not None:
+            unused_ok = unused_ok and q_.grad is not None and bool(torch.allclose(p.grad, q_.grad, rtol=1e-5, atol=1e-7))
+    sync_u.remove()
+    e_ = _Toy(with_unused=True)
+    strict = NativeGradSync(e_, world, process_group=dist.new_group())
+    e_(xs[0]).backward()
+    try:
+        strict.finish()
+        unused_ok = False
+    except RuntimeError as err:
+        unused_ok = unused_ok and "visual.unused" in str(err)
     q.put((rank, same_start, unused_ok, g1, g2, dict(sync.stats)))
     dist.barrier()
     dist.destroy_process_group()

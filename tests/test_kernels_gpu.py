@@ -99,8 +99,12 @@ def test_probe_tr16_layout(dev):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (400, 384, 192), (1000, 2304, 768), (77 * 8, 512, 2048), (37, 6, 64), (4096, 4096, 512)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (400, 384, 192), (1000, 2304, 768), (77 * 8, 512, 2048), (37, 6, 64), (4096, 4096, 512),
+                                   (1300, 520, 128), (3000, 264, 256), (70000, 776, 384)])
 def test_gemm_nt_epilogues(dev, M, N, K):
+    """every epilogue against fp32 torch.  The last three shapes are for the persistent kernel's epilogue-operand prefetch (round 4): K = 128 is a
+    tile of ONE K-tile pair (the prefetch is issued in a tile's first phase), K = 256 two pairs, N % 16 == 8 puts the end of a row inside a lane's
+    16-byte piece of the saved gelu', and 70000 x 776 gives every workgroup several tiles (the prefetch crosses tile boundaries)"""
     from open_clip_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
     a = bf(torch.randn(M, K, generator=g)).to(dev)
