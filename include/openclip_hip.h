@@ -95,12 +95,17 @@ int ocn_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, ocn_s
  *      (either pointer may be NULL) and mean/rstd [M] for the backward.
  * bwd: dx = LN'(dy) (+ dres if non-NULL: the residual branch's gradient), written as fp32 and/or bf16;
  *      dw[C] += sum_rows dy*xhat, db[C] += sum_rows dy (fp32 atomics; caller zeroes).
- *      dy is bf16 (dy_is_f32 = 0) or fp32 (1). */
+ *      dy is bf16 (dy_is_f32 = 0) or fp32 (1).
+ *      dcol (may be NULL): dcol[C] += sum_rows dx in fp32, before dx is rounded to bf16.  dx is the gradient of the output of the linear
+ *      in front of this LayerNorm's input (out_proj, or the previous block's c_proj: transformer.py:246, :299), so this is that layer's bias
+ *      gradient summed from fp32 values instead of from the bf16 operand of its weight-gradient GEMM.
+ * ocn_colsum_f32: out[C] += sum_rows x[R, C] (fp32; the same for tensors no LayerNorm backward produces). */
 int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
                       float* rstd, int M, int C, float eps, ocn_stream_t stream);
 int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                      const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, int M,
-                      int C, ocn_stream_t stream);
+                      const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, float* dcol,
+                      int M, int C, ocn_stream_t stream);
+int ocn_colsum_f32(const float* x, float* out, int R, int C, ocn_stream_t stream);
 /* ---- attention core (transformer.py:199-244: head split + F.scaled_dot_product_attention) ------
  * qkv bf16 [B*L, 3*H*64] (q | k | v column blocks, heads contiguous inside each: the layout F.linear with
  * in_proj_weight produces, transformer.py:169); out bf16 [B*L, H*64]; lse fp32 [B*H*L] (natural log).
@@ -110,10 +115,12 @@ int ocn_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, in
                  ocn_stream_t stream);
 int ocn_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int L, int H,
                  int causal, float scale, ocn_stream_t stream);
-/* The same with an explicit head_dim (64, 80, 96 or 128; qkv [B*L, 3*H*head_dim]): head_dim 64 with L <= 320 runs the
- * kernels above, everything else (ViT-H-14: head_dim 80, 257 tokens) the K/V-resident query-tiled kernels of
- * csrc/attention_generic.hip, which need 2 * roundup(L,32) * roundup(head_dim,32) * 2 bytes <= 160 KiB of LDS.  The backward's
- * workspace `delta_ws` is fp32 [B*H*L] (sum_d dO*O, exchanged between its two launches; may be NULL on the head_dim-64 path). */
+/* The same with an explicit head_dim (64, 80, 88, 96, 104, 112 or 128; qkv [B*L, 3*H*head_dim]): head_dim 64 up to 128 tokens (forward)
+ * / 320 tokens (backward) runs the head-resident kernels above, everything else (ViT-H-14: head_dim 80, 257 tokens; ViT-L-14's 257 tokens;
+ * ViT-g / bigG / e: head_dim 88 / 104 / 112) the STREAMED kernels of csrc/attention_generic.hip: 4-wave workgroups that own four 32-row
+ * blocks and stream the operand all of them need through a two-slot LDS ring in 64-row chunks (18-35 KB of LDS per workgroup, any
+ * sequence length).  The backward's workspace `delta_ws` is fp32 [B*H*L] (sum_d dO*O, exchanged between its launches; may be NULL on the
+ * head-resident path). */
 int ocn_attn_fwd_hd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, int causal, float scale,
                     ocn_stream_t stream);
 int ocn_attn_bwd_hd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int L,
@@ -131,6 +138,18 @@ int ocn_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int32_t* s
 int ocn_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const int32_t* seq_off,
                         const int32_t* order, const int32_t* bucket_counts, int B, int Lmax, int H, int causal, float scale,
                         ocn_stream_t stream);
+
+/* Single-query attention of a tower's LAST block, head_dim 64 (csrc/attention_pooled.hip).  Both poolers read one row per sequence of the
+ * last block's output (transformer.py:829-831 `x[:, 0]`, :941-944 `x[arange, text.argmax(-1)]`), and rows only mix inside the attention: of
+ * that block's attention exactly one query per (sequence, head) is needed.  q / out / dout / dq are [B, H*64] (the pooled rows), kv / dkv
+ * [M, 2*H*64] (K | V column blocks of EVERY row: F.linear with in_proj_weight[C:], transformer.py:169), lse fp32 [B*H].  Sequence b owns rows
+ * seq_off[b] .. seq_off[b+1] of kv (packed text rows) or, with seq_off = NULL, rows b*L .. (b+1)*L; rows[b] = absolute row of its pooled
+ * token, which under `causal` sees the keys up to and including its own row.  The backward writes every key row of dkv (zeros behind the
+ * pooled row). */
+int ocn_attn_pooled_fwd(const void* q, const void* kv, void* out, float* lse, const int32_t* seq_off, const int32_t* rows, int B, int L,
+                        int H, int causal, float scale, ocn_stream_t stream);
+int ocn_attn_pooled_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse, void* dq, void* dkv,
+                        const int32_t* seq_off, const int32_t* rows, int B, int L, int H, int causal, float scale, ocn_stream_t stream);
 
 /* ---- image tower embedding (transformer.py:793-808) -------------------------------------------
  * patchify: image [B,3,H,W] (fp32, or bf16 when image_is_bf16) -> patches bf16 [B*gh*gw, Kpad], column order
@@ -199,18 +218,22 @@ int ocn_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float
 /* ---- contrastive losses on materialised logits -------------------------------------------------
  * softmax CE rows (F.cross_entropy(logits, arange+offset), loss.py:78-89,136-139): for each of R rows of
  *   logits fp32 [R,N]: lse, loss_sum += (lse - logits[r, r+label_offset]) * loss_scale; writes
- *   G bf16 [R,N] = (softmax - onehot) * grad_scale; dscale_sum += sum(G*logits) * inv_logit_scale.
+ *   G bf16 [R,N] = softmax * grad_scale -- the -onehot * grad_scale part of the logit gradient is NOT stored: the caller applies it exactly in
+ *   fp32 (dX_r -= grad_scale * Y[r + label_offset], dY[r + label_offset] -= grad_scale * X_r): rounded to bf16 the label entry
+ *   (p - 1) * grad_scale loses its p, a bias of the same sign in every row that every sum over the batch adds up coherently;
+ *   dscale_sum += sum((softmax - onehot) * grad_scale * logits) * inv_logit_scale.
  * siglip (loss.py:344-367): z = labels*logits (labels -1 off-diagonal, +1 on (r, r+label_offset) unless
- *   negative_only); loss_sum += -logsigmoid(z)*loss_scale; G = -labels*sigmoid(-z)*grad_scale;
- *   dscale_sum += sum(G*(logits-bias))*inv_logit_scale; dbias_sum += sum(G). */
+ *   negative_only); loss_sum += -logsigmoid(z)*loss_scale; with g = -labels*sigmoid(-z) = sigmoid(logits) - [positive]: G =
+ *   sigmoid(logits)*grad_scale (the positives' -grad_scale is the caller's, exact, as for the cross-entropy);
+ *   dscale_sum += sum(g*grad_scale*(logits-bias))*inv_logit_scale; dbias_sum += sum(g*grad_scale). */
 int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, float loss_scale,
                         float grad_scale, float inv_logit_scale, float* loss_sum, float* dscale_sum,
                         ocn_stream_t stream);
 /* The same cross-entropy WITHOUT materialised logits (loss.py:103-110 + :136-139 for a [R, N] block of logits_per_image / _per_text;
  * the row-sharded global loss of 8 GPUs has R = 4096, N = 32768): X bf16 [R, E] (already times logit_scale), Y bf16 [N, E]; two passes
- * of the MFMA GEMM consume the fp32 logits tile in registers (online log-sum-exp, then G = (softmax - onehot) * grad_scale as bf16
- * [R, ldg]); loss_sum += sum_r (lse_r - logit[r, r + label_offset]) * loss_scale; dscale_sum += sum(G * logits) (divide by
- * logit_scale for d/d logit_scale).  E % 128 == 0, N % 8 == 0; `workspace` = ocn_fused_logits_ce_workspace_floats(R, N) floats. */
+ * of the MFMA GEMM consume the fp32 logits tile in registers (online log-sum-exp, then G = softmax * grad_scale as bf16 [R, ldg]; the
+ * onehot part is the caller's, as above); loss_sum += sum_r (lse_r - logit[r, r + label_offset]) * loss_scale; dscale_sum +=
+ * sum((softmax - onehot) * grad_scale * logits) (divide by logit_scale for d/d logit_scale).  E % 128 == 0, N % 8 == 0; `workspace` = ocn_fused_logits_ce_workspace_floats(R, N) floats. */
 int64_t ocn_fused_logits_ce_workspace_floats(int R, int N);
 int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
                         float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
@@ -254,6 +277,8 @@ int ocn_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_
 int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream);
 /* in-place MEAN over ranks (ncclAvg): the gradient all-reduce that replaces DistributedDataParallel's reducer (base_task.py:219-232) */
 int ocn_comm_allreduce_avg(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream);
+/* buf [count] on every rank = rank `root`'s, in place (ncclBroadcast): the parameter broadcast at the start of training (DDP's, base_task.py:227) */
+int ocn_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, ocn_stream_t stream);
 
 /* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
 int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,

@@ -23,13 +23,16 @@ SIGNATURES = {
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
     "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
-    "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ocn_colsum_f32": [_p, _p, _i, _i, _p],
     "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_fwd_hd": [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd_hd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "ocn_attn_fwd_varlen": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd_varlen": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_pooled_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ocn_attn_pooled_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "ocn_patchify_u8": [_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _p, _i, _i, _i, _i, _i, _p],
     "ocn_embed_assemble_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -63,6 +66,7 @@ SIGNATURES = {
     "ocn_comm_reduce_scatter_sum": [_p, _p, _p, _l, _i, _p],
     "ocn_comm_allreduce_sum": [_p, _p, _l, _i, _p],
     "ocn_comm_allreduce_avg": [_p, _p, _l, _i, _p],
+    "ocn_comm_broadcast": [_p, _p, _l, _i, _i, _p],
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }

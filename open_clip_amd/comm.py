@@ -71,9 +71,12 @@ class NativeComm:
     def all_reduce_avg(self, t):
         _lib.call("ocn_comm_allreduce_avg", self._comm, _check(t, "tensor"), t.numel(), _dt(t), self._stream())
 
+    def broadcast(self, t, root=0):
+        _lib.call("ocn_comm_broadcast", self._comm, _check(t, "tensor"), t.numel(), _dt(t), int(root), self._stream())
+
     def close(self):
-        """destroys the communicator; pending collectives are waited for first (ncclCommDestroy does not order itself behind the streams)"""
+        """destroys the communicator; pending collectives are waited for first (ncclCommDestroy does not order itself behind the streams:
+        ocn_comm_destroy drains the device before it calls it)"""
         if self._comm:
-            torch.cuda.synchronize()
             _lib.call("ocn_comm_destroy", self._comm)
             self._comm = None

@@ -23,6 +23,7 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -43,6 +44,7 @@ Rccl* rccl() {
     *(void**)&r.AllGather = dlsym(r.handle, "ncclAllGather");
     *(void**)&r.ReduceScatter = dlsym(r.handle, "ncclReduceScatter");
     *(void**)&r.AllReduce = dlsym(r.handle, "ncclAllReduce");
+    *(void**)&r.Broadcast = dlsym(r.handle, "ncclBroadcast");
     *(void**)&r.GetErrorString = dlsym(r.handle, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.ReduceScatter || !r.AllReduce) r.handle = nullptr;
     return r.handle ? &r : nullptr;
@@ -86,6 +88,12 @@ extern "C" int ocn_comm_init(const void* id_128, int rank, int world, void** com
 extern "C" int ocn_comm_destroy(void* comm) {
     Rccl* R = rccl();
     OCN_CHECK_ARG(R && comm, "ocn_comm_destroy: bad arguments");
+    // ncclCommDestroy does not order itself behind the streams its collectives were enqueued on: drain the device first, here, so that no
+    // caller can destroy a communicator under a running collective
+    if (hipDeviceSynchronize() != hipSuccess) {
+        ocn_set_error("ocn_comm_destroy: hipDeviceSynchronize failed");
+        return OCN_ERR_LAUNCH;
+    }
     OCN_RCCL(R->CommDestroy((Comm)comm), "ocn_comm_destroy");
     return OCN_OK;
 }
@@ -111,6 +119,15 @@ extern "C" int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int 
     Rccl* R = rccl();
     OCN_CHECK_ARG(R && comm && buf && count > 0, "ocn_comm_allreduce_sum: bad arguments");
     OCN_RCCL(R->AllReduce(buf, buf, (size_t)count, dtype_of(dtype), kSum, (Comm)comm, (hipStream_t)stream), "ocn_comm_allreduce_sum");
+    return OCN_OK;
+}
+
+// buf [count] on every rank = buf of rank `root`, in place (ncclBroadcast): the start-of-training parameter broadcast (what DDP does at
+// construction, base_task.py:227) -- exact for every dtype, one collective per tensor
+extern "C" int ocn_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, ocn_stream_t stream) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && R->Broadcast && comm && buf && count > 0 && root >= 0, "ocn_comm_broadcast: bad arguments");
+    OCN_RCCL(R->Broadcast(buf, buf, (size_t)count, dtype_of(dtype), root, (Comm)comm, (hipStream_t)stream), "ocn_comm_broadcast");
     return OCN_OK;
 }
 

@@ -15,6 +15,9 @@ struct GemmNtArgs {
     int stagger; // start offset between the 4 phase classes of workgroups, in 100 MHz ticks (0 = none; gemm_nt5.hip)
     int first_wave;  // workgroups [0, first_wave) start together (one per CU) and are the ones that get staggered
     int band;    // tile walk order: column bands of `band` n-tiles, row-major inside a band (gemm_nt5.hip)
+    // the launch's last, partial round of tiles computed as HALF tiles (gemm_nt5.hip; set by launch5, 0 = off): tiles [tail_first, tail_first +
+    // tail_n) of the walk are split; workgroup j < tail_n takes the upper half of tail tile j, workgroup tail_partner + j the lower half
+    int tail_first, tail_n, tail_partner;
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
     // fused logits + cross-entropy epilogues (OCN_EPI_CE_STATS / OCN_EPI_CE_GRAD below; ocn_fused_logits_ce in loss.hip)
     float* ce_stats;        // STATS: [M][ce_parts][2] per-row (max, sum exp) of each 64-column strip

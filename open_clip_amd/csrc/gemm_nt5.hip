@@ -103,15 +103,15 @@ struct NtPf {
 };
 
 // byte offset of this lane's 4 fp32 columns in row it*8 + (lane >> 3) of 32 x 32 block blk (fp32-staged epilogues, residual prefetch)
-OCN_DEV unsigned f32blk_off(const GemmNtArgs& a, int lane_o, int wm, int gn_w, int blk, int it, unsigned esz) {
+OCN_DEV unsigned f32blk_off(const GemmNtArgs& a, int lane_o, int row_w, int gn_w, int blk, int it, unsigned esz) {
     const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
     const int gn = gn_w + hb * 32 + (lane_o & 7) * 4;
-    const int row = wm * 128 + ha * 64 + s * 32 + it * 8 + (lane_o >> 3);
+    const int row = row_w + ha * 64 + s * 32 + it * 8 + (lane_o >> 3);
     return ((unsigned)(row * a.ldc + gn) * esz) | (gn < a.N ? 0u : OOB);  // OOB: past the descriptor's bound (no select, no branch)
 }
 
 template <int EPI, int AUX>
-OCN_DEV void epi_prefetch(const GemmNtArgs& a, int m0, int n0, int wm, int wn, int lane, u32x4 (&pf)[8]) {
+OCN_DEV void epi_prefetch(const GemmNtArgs& a, int m0, int n0, int row_w, int wn, int lane, u32x4 (&pf)[8]) {  // row_w: the wave's first row inside the tile
     if constexpr (NtPf<EPI>::N > 0) {
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // see epilogue5: keeps the address arithmetic out of the tile loop's live set
@@ -120,7 +120,7 @@ OCN_DEV void epi_prefetch(const GemmNtArgs& a, int m0, int n0, int wm, int wn, i
         if constexpr (EPI == OCN_EPI_DGELU) {
             const __amdgpu_buffer_rsrc_t r_aux = tile_rsrc(a.aux, m0, m_ld, a.ldc, 1);
             const int gn = gn_w + (lane_o & 3) * 16;
-            const unsigned base = (unsigned)((wm * 128 + (lane_o >> 2)) * a.ldc + gn) | (gn < a.N ? 0u : OOB);
+            const unsigned base = (unsigned)((row_w + (lane_o >> 2)) * a.ldc + gn) | (gn < a.N ? 0u : OOB);
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r_aux, base + (unsigned)(j * 16 * a.ldc), 0, (AUX & 8) ? 2 : 0);
         } else {
@@ -129,7 +129,7 @@ OCN_DEV void epi_prefetch(const GemmNtArgs& a, int m0, int n0, int wm, int wn, i
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
-                    pf[blk * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(r_res, f32blk_off(a, lane_o, wm, gn_w, blk, it, 4u), 0, (AUX & 8) ? 2 : 0);
+                    pf[blk * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(r_res, f32blk_off(a, lane_o, row_w, gn_w, blk, it, 4u), 0, (AUX & 8) ? 2 : 0);
         }
     }
 }
@@ -149,7 +149,9 @@ OCN_DEV void lds_r32x8(unsigned a0, unsigned (&q)[2][4]) {  // the lane's four 4
 
 template <int EPI, int AUX = 0>
 OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg, u32x4 (&pf)[8],
-                       long long* dbg = nullptr) {
+                       int ha_n, int row_shift, long long* dbg = nullptr) {
+    // ha_n / row_shift: 2 / 0 for a whole 256 x 256 tile; 1 / 0 or 64 for a HALF tile of the launch's last round (see the kernel): only acc[0]
+    // holds results, for rows wm*128 + row_shift + 0..63
     // Lane constants are laundered through an empty asm once per tile: otherwise hipcc hoists ~40 VGPRs of epilogue
     // addresses (per-row store offsets, swizzled staging addresses) out of the tile loop and keeps them live across the
     // main loop, which is already at the 256-register budget.
@@ -241,9 +243,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         for (int r = 0; r < 16; ++r) {
                             const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
                             const float v = acc[ha][s][hb][r];
-                            const float gv = (__expf(v - lse) - (col == label ? 1.f : 0.f)) * a.ce_grad_scale;
-                            if (row < a.M && col < a.N) ds += gv * v;
-                            acc[ha][s][hb][r] = gv;  // stored as bf16 by the staged path below
+                            // G holds softmax * grad_scale ONLY; the -onehot * grad_scale term of the logit gradient is applied by the caller as an
+                            // exact rank-1 update in fp32 (loss.py::_PairTerm): rounded to bf16 the label entry (p - 1) * gs loses its p -- every row
+                            // sum of G is then off by -p_label * gs, a COMMON-MODE bias of the feature gradients that every sum over the batch (all
+                            // bias / LayerNorm gradients) adds up coherently (round 4: it doubled the error of every parameter gradient at batch 4096)
+                            const float pe = __expf(v - lse);
+                            if (row < a.M && col < a.N) ds += (pe - (col == label ? 1.f : 0.f)) * a.ce_grad_scale * v;
+                            acc[ha][s][hb][r] = pe * a.ce_grad_scale;  // stored as bf16 by the staged path below
                         }
                 }
             }
@@ -260,7 +266,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     // ordinary counted waits.)  This is also where the operands the main loop fetched ahead (pf) are waited for.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (dbg) dbg[5] = wall_clock64();
-    const int row_w = wm * 128;  // this wave's first row inside the tile
+    const int row_w = wm * 128 + row_shift;  // this wave's first row inside the tile
     if (BF16_STAGED) {
         const int gn = gn_w + rd_chunk * 8;
         const unsigned col_off = gn < a.N ? (unsigned)gn * 2u : OOB;
@@ -270,7 +276,8 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         const unsigned aw_addr = stg + lr * 72 + lh * 4, ar_addr = stg + rd_row * 72 + rd_chunk * 8;
         const unsigned dw_addr = stg + (lane_o >> 2) * 72 + (lane_o & 3) * 16;
 #pragma unroll
-        for (int ha = 0; ha < 2; ++ha)
+        for (int ha = 0; ha < 2; ++ha) {
+            if (ha >= ha_n) break;  // uniform
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // GELU: gelu(v) AND gelu'(v) come out of one evaluation of the shared erf / exp parts; the derivative is what
@@ -336,6 +343,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     }
                 }
             }
+        }
     } else {
         // 32x32 fp32 blocks (128-byte rows).  The residual rows of block k + DEPTH - 1 are requested before block k's stores are issued: vmcnt
         // retires loads AND stores in issue order, so waiting for a block's operand also waits for every store issued before its request -- with a
@@ -346,7 +354,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         auto load_ex = [&](int blk, f32x4 (&e)[4]) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                e[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, f32blk_off(a, lane_o, wm, gn_w, blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
+                e[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, f32blk_off(a, lane_o, row_w, gn_w, blk, it, 4u), 0, (AUX & 8) ? 2 : 0));
         };
         if constexpr (HAS_EX) {
 #pragma unroll
@@ -357,6 +365,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         }
 #pragma unroll
         for (int blk = 0; blk < 8; ++blk) {
+            if (blk >= 4 * ha_n) break;  // uniform
             const int ha = blk >> 2, s = (blk >> 1) & 1, hb = blk & 1;
             if (dbg && blk == 4) dbg[6] = wall_clock64();
 #pragma unroll
@@ -367,12 +376,12 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
             f32x4 d[4];
             lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
             if constexpr (HAS_EX) {
-                if (blk + DEPTH - 1 < 8) load_ex(blk + DEPTH - 1, ex[(blk + DEPTH - 1) % DEPTH]);
+                if (blk + DEPTH - 1 < 4 * ha_n) load_ex(blk + DEPTH - 1, ex[(blk + DEPTH - 1) % DEPTH]);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const f32x4 v = (EPI == OCN_EPI_F32) ? d[it] * a.alpha + bq[hb] : d[it] + bq[hb];
-                const unsigned off = f32blk_off(a, lane_o, wm, gn_w, blk, it, 4u) & omask;
+                const unsigned off = f32blk_off(a, lane_o, row_w, gn_w, blk, it, 4u) & omask;
                 if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v + ex[blk % DEPTH][it]), r_out, off, 0, AUX & 2);
                 } else {
@@ -395,7 +404,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = a.K >> 6;  // K-tiles per output tile (even)
     const int G = gridDim.x;
-    const int my_tiles = (a.ntiles - (int)blockIdx.x + G - 1) / G;
+    // a.tail_n > 0: the launch's last, partial round of tiles is split into HALF tiles (see below); the whole tiles are then exactly a.tail_first / G per
+    // workgroup
+    const int my_tiles = a.tail_n > 0 ? a.tail_first / G : (a.ntiles - (int)blockIdx.x + G - 1) / G;
     const unsigned lds_base = (unsigned)(size_t)(OCN_LDS char*)smem;
 
     // fragment read addresses: unit row (wave strip + lane&31), 16-byte chunk ((ks*2 + lh) ^ swz) = (q<<4) ^ (ks<<5)
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         acc[0][1][1] = mfma32(fb[1][0], fa[0][1], acc[0][1][1]);                                  \
         PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
         RD_A(fa[0], 2, 0, P) RD_B(2, P)                                                           \
-        if ((PFM) == 1) epi_prefetch<EPI, AUX>(a, pm0, pn0, wm, wn, lane, pf);                    \
+        if ((PFM) == 1) epi_prefetch<EPI, AUX>(a, pm0, pn0, wm * 128, wn, lane, pf);              \
         SB(); PRIO_ON()                                                                                     \
         MM(0, fa[1], 1)                                                                           \
         PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
@@ -673,10 +684,91 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
             KTILE(1, false, true, 2)
         }
         STAMP(3)
-        epilogue5<EPI, AUX>(a, acc, pm0, pn0, wm, wn, lane, stg, pf, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
+        epilogue5<EPI, AUX>(a, acc, pm0, pn0, wm, wn, lane, stg, pf, 2, 0, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
         if (ABL(a, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // developer knob: let the tile's stores drain before the next main loop
         if constexpr (PFN > 0) __builtin_amdgcn_s_barrier();  // publishes the next tile's first K-tile (see KTILE, PFM = 2)
         STAMP(4)
+    }
+    // ---- the launch's last round, in HALF tiles ---------------------------------------------------------------------------
+    // ntiles is rarely a multiple of the grid: the N = 768 GEMMs of ViT-B-32 at batch 4096 have 2400 tiles for 256 CUs -- nine full rounds and
+    // a tenth in which 96 workgroups compute a whole tile each while 160 CUs idle (6 % of the launch; 8.5 % for the text tower's N = 512
+    // shapes).  When at most half of the workgroups would get a tail tile, each tail tile is split into its two 128 x 256 halves -- the rows
+    // {wm*128 + h*64 + 0..63}, i.e. the A0 (h = 0) or A1 (h = 1) operand unit of every wave's strip -- and 2R workgroups compute one half each:
+    // half the MFMAs of a tile on 3/4 of its operand bytes, no exchange between workgroups, nothing to reduce.  A half tile is ONE phase per
+    // K-tile (16 MFMAs per wave: A x (B0, B1) with the B fragments read as they are used) and one barrier: the slot of K-tile g is free once
+    // every wave has read its last fragments, which is where the barrier sits, and is refilled right behind it -- B two K-tiles ahead (it comes
+    // from L2), A four K-tiles ahead through the two A units a half tile does not otherwise need (it comes from HBM).
+    if constexpr (EPI != OCN_EPI_CE_STATS && EPI != OCN_EPI_CE_GRAD) if (a.tail_n > 0) {
+        int t = -1, h = 0;
+        if ((int)blockIdx.x < a.tail_n) t = (int)blockIdx.x;
+        else if ((int)blockIdx.x >= a.tail_partner && (int)blockIdx.x < a.tail_partner + a.tail_n) { t = (int)blockIdx.x - a.tail_partner; h = 1; }
+        if (t >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave has left the ring of the last whole tile
+            int m0, n0;
+            {
+                const int tile = xcd_remap(t + a.tail_first, a.ntiles);
+                const int cb = tile / band_tiles, r = tile - cb * band_tiles;
+                const int width = min(a.band, a.tiles_n - cb * a.band);
+                const int mi = r / width;
+                m0 = mi * 256;
+                n0 = (cb * a.band + (r - mi * width)) * 256;
+            }
+            dA0 = make_desc(a.A, m0, a.M, a.lda);
+            dB = make_desc(a.B, n0, a.N, a.ldb);
+            const unsigned hoff = h ? a_half : 0u;  // this half's rows: the A1 unit's offset
+            unsigned kb = 0, ka = 0;                // byte offsets of the K-tiles the B / A cursors issue next (clamped at the end: junk, never read)
+            const unsigned k_last = k_end - 128u;
+#define HDMA_A(SLOT) { const unsigned so_ = (ka < k_end ? ka : k_last) + hoff; DMA(dA0, voA, so_, SLOT, 0) DMA(dA0, voA, so_, SLOT, 1) ka += 128; }
+#define HDMA_B(P) { const unsigned so_ = kb < k_end ? kb : k_last; DMA(dB, voB, so_, B_SLOT(0, P), 0) DMA(dB, voB, so_, B_SLOT(0, P), 1) \
+                    DMA(dB, voB, so_ + b_half, B_SLOT(1, P), 0) DMA(dB, voB, so_ + b_half, B_SLOT(1, P), 1) kb += 128; }
+            HDMA_A(A_SLOT(0, 0)) HDMA_B(0) HDMA_A(A_SLOT(0, 1)) HDMA_B(1) HDMA_A(A_SLOT(1, 0)) HDMA_A(A_SLOT(1, 1))
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][y][z][r] = 0.f;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            SB();
+            RD_A(fa[0], 0, 0, 0) RD_B(0, 0)
+            LGKM0();
+            SB();
+            // K-tile g = 4 n + Q: A unit in ring slot Q (= A_SLOT(Q >> 1, Q & 1)), B units in parity Q & 1
+#define HKT(Q)                                                                                          \
+    {                                                                                                   \
+        RD_A(fa[1], 1, (Q) >> 1, (Q) & 1) RD_B(1, (Q) & 1)                                              \
+        SB();                                                                                           \
+        MM(0, fa[0], 0)                                                                                 \
+        SB(); LGKM0(); SB();                                                                            \
+        RD_A(fa[0], 2, (Q) >> 1, (Q) & 1) RD_B(2, (Q) & 1)                                              \
+        SB();                                                                                           \
+        MM(0, fa[1], 1)                                                                                 \
+        SB(); LGKM0(); SB();                                                                            \
+        RD_A(fa[1], 3, (Q) >> 1, (Q) & 1) RD_B(3, (Q) & 1)                                              \
+        SB();                                                                                           \
+        MM(0, fa[0], 2)                                                                                 \
+        SB(); LGKM0(); SB();                                                                            \
+        /* this wave has read the last fragment of K-tile g; its own pieces of K-tile g + 1 have landed when at most the two A pieces issued */ \
+        /* one K-tile ago are still in flight (the B pieces are issued in front of them) */            \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        SB();                                                                                           \
+        HDMA_B((Q) & 1)                                                                                 \
+        HDMA_A(A_SLOT((Q) >> 1, (Q) & 1))                                                               \
+        RD_A(fa[0], 0, (((Q) + 1) & 3) >> 1, ((Q) + 1) & 1) RD_B(0, ((Q) + 1) & 1)                      \
+        SB();                                                                                           \
+        MM(0, fa[1], 3)                                                                                 \
+        SB(); LGKM0(); SB();                                                                            \
+    }
+            for (int kt = 0; kt < nk; kt += 4) { HKT(0) HKT(1) HKT(2) HKT(3) }
+#undef HKT
+#undef HDMA_A
+#undef HDMA_B
+            epi_prefetch<EPI, AUX>(a, m0, n0, wm * 128 + h * 64, wn, lane, pf);
+            epilogue5<EPI, AUX>(a, acc, m0, n0, wm, wn, lane, stg, pf, 1, h * 64);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released
 #undef KTILE
@@ -765,6 +857,19 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     // more than collectives that are active for ~1.5 % of a step can take back -- so k = 1 stays the default.
     const int per_cu = g_ocn_tuning[10] > 0 ? g_ocn_tuning[10] : 1;
     const int grid = a.ntiles < g_num_cu * per_cu ? a.ntiles : g_num_cu * per_cu;
+    // The last, partial round of tiles as half tiles (see the kernel): when R = ntiles mod grid tiles are left over for at most half of the
+    // workgroups, 2R workgroups compute a 128 x 256 half each -- the two halves of a tile on the same XCD (partner offset a multiple of 8).
+    // Developer knob 12 = 1 (OCN_DEV_BUILD): whole tail tiles as before (A/B).
+    a.tail_first = a.tail_n = a.tail_partner = 0;
+    {
+        const int R = a.ntiles % grid, P = (R + 7) / 8 * 8;
+        constexpr bool ce = (EPI == OCN_EPI_CE_STATS || EPI == OCN_EPI_CE_GRAD);  // their row statistics are laid out per whole tile
+        if (!ce && a.ntiles > grid && R > 0 && R + P <= grid && (a.K / 64) % 4 == 0 && !ABL(a, 0x200000)) {
+            a.tail_first = a.ntiles - R;
+            a.tail_n = R;
+            a.tail_partner = P;
+        }
+    }
     // Cache policy of the epilogue (template parameter AUX: bit 1 (2) = non-temporal stores, bit 3 (8) = non-temporal loads of the
     // residual / saved derivative; profiles/r01_nt5_cache_policy_sweep.txt, profiles/r04_nt5_epilogue_prefetch.txt):
     //   stores: non-temporal for the two-output GELU epilogue (256 KiB per tile that nothing re-reads before they are long evicted:

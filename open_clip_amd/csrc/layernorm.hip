@@ -77,22 +77,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 template <int NV>
 constexpr int ln_bwd_waves() { return NV <= 3 ? 16 : (NV <= 5 ? 12 : 8); }  // what the registers of a row's NV x 16 bytes per lane leave room for
 
-template <int NV, bool DY32, bool NT>
+// CS: additionally dcol[c] += sum over rows of dx[row, c] in fp32, BEFORE dx is rounded to its bf16 twin.  dx is the gradient of the output of the
+// linear layer in front of this LayerNorm's input (out_proj resp. the previous block's c_proj), so this IS that layer's bias gradient
+// (transformer.py:246, :299) -- summed from fp32 values instead of from the bf16 operand of the weight-gradient GEMM: bias gradients are column
+// sums with heavy cancellation across a contrastive batch, and at batch 4096 the rounding of the summands alone put them at 1.0 of their
+// parity bound (profiles/r04_parity_report.txt).
+template <int NV, bool DY32, bool NT, bool CS>
 __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const void* __restrict__ dyv, const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
                                                       float* __restrict__ dx32, bf16* __restrict__ dx16,
-                                                      float* __restrict__ dw, float* __restrict__ db, int M, int C) {
+                                                      float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dcol, int M, int C) {
     constexpr int BW = ln_bwd_waves<NV>();
-    __shared__ float red[(BW + 1) / 2][NV * 256 * 2];
+    constexpr int NS = CS ? 3 : 2;  // sums per column: dgamma, dbeta (, dx)
+    __shared__ float red[(BW + 1) / 2][NV * 256 * NS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invC = 1.0f / (float)C;
-    f32x4 aw[NV], ab[NV], wv[NV];
+    f32x4 aw[NV], ab[NV], ac[CS ? NV : 1], wv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         aw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         ab[i] = aw[i];
+        if (CS) ac[i] = aw[i];
         wv[i] = (c < C) ? *(const f32x4*)(w + c) : aw[i];
     }
     for (int row = blockIdx.x * BW + wave; row < M; row += gridDim.x * BW) {
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
                 o = o + dr[i];
+                if (CS) ac[i] = ac[i] + o;
                 if (dx32) {
                     if (NT) __builtin_nontemporal_store(o, (f32x4*)(dx32 + (size_t)row * C + c));
                     else *(f32x4*)(dx32 + (size_t)row * C + c) = o;
@@ -158,8 +166,9 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
             for (int i = 0; i < NV; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    red[wave - half][((i * 4 + e) * 64 + lane) * 2] = aw[i][e];
-                    red[wave - half][((i * 4 + e) * 64 + lane) * 2 + 1] = ab[i][e];
+                    red[wave - half][((i * 4 + e) * 64 + lane) * NS] = aw[i][e];
+                    red[wave - half][((i * 4 + e) * 64 + lane) * NS + 1] = ab[i][e];
+                    if (CS) red[wave - half][((i * 4 + e) * 64 + lane) * NS + 2] = ac[i][e];
                 }
         }
         __syncthreads();
@@ -168,8 +177,9 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
             for (int i = 0; i < NV; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    aw[i][e] += red[wave][((i * 4 + e) * 64 + lane) * 2];
-                    ab[i][e] += red[wave][((i * 4 + e) * 64 + lane) * 2 + 1];
+                    aw[i][e] += red[wave][((i * 4 + e) * 64 + lane) * NS];
+                    ab[i][e] += red[wave][((i * 4 + e) * 64 + lane) * NS + 1];
+                    if (CS) ac[i][e] += red[wave][((i * 4 + e) * 64 + lane) * NS + 2];
                 }
         }
         __syncthreads();
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                 if (c < C) {
                     unsafeAtomicAdd(dw + c + e, aw[i][e]);
                     unsafeAtomicAdd(db + c + e, ab[i][e]);
+                    if (CS) unsafeAtomicAdd(dcol + c + e, ac[i][e]);
                 }
             }
         }
@@ -217,17 +228,38 @@ void launch_fwd(hipStream_t st, const float* x, const float* w, const float* b, 
     else
         ln_fwd_kernel<NV, true><<<g, t, 0, st>>>(x, w, b, y16, y32, mean, rstd, M, C, eps);
 }
+template <int NV, bool DY32, bool NT, bool CS>
+void launch_bwd4(hipStream_t st, const void* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* dres, float* dx32,
+                 bf16* dx16, float* dw, float* db, float* dcol, int M, int C) {
+    ln_bwd_kernel<NV, DY32, NT, CS><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, M, C);
+}
 template <int NV>
 void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, int M, int C) {
+                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, float* dcol, int M, int C) {
     const bool nt = g_ocn_tuning[8] != 1;  // developer knob 8 = 1: default cache policy everywhere
-    if (dy_is_f32) {
-        if (nt) ln_bwd_kernel<NV, true, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
-        else ln_bwd_kernel<NV, true, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
-    } else {
-        if (nt) ln_bwd_kernel<NV, false, true><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
-        else ln_bwd_kernel<NV, false, false><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, M, C);
+#define OCN_LN_BWD(DY32, NT)                                                                                                  \
+    {                                                                                                                         \
+        if (dcol) launch_bwd4<NV, DY32, NT, true>(st, dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, M, C);             \
+        else launch_bwd4<NV, DY32, NT, false>(st, dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, M, C);                 \
     }
+    if (dy_is_f32) {
+        if (nt) OCN_LN_BWD(true, true) else OCN_LN_BWD(true, false)
+    } else {
+        if (nt) OCN_LN_BWD(false, true) else OCN_LN_BWD(false, false)
+    }
+#undef OCN_LN_BWD
+}
+
+// out[c] += sum over rows of x[r, c] (fp32): the bias gradients of the B pooled rows' linears (model.py::_PooledBlockFn), summed from fp32 values
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < C)
+        for (int r = blockIdx.y * 4 + grp; r < R; r += gridDim.y * 4) s += x[(size_t)r * C + col];
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && col < C) unsafeAtomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 }  // namespace
@@ -250,20 +282,28 @@ extern "C" int ocn_layernorm_fwd(const float* x, const float* w, const float* b,
     return OCN_OK;
 }
 
+extern "C" int ocn_colsum_f32(const float* x, float* out, int R, int C, ocn_stream_t stream) {
+    OCN_CHECK_ARG(x && out && R > 0 && C > 0, "ocn_colsum_f32: bad operand (R=%d C=%d)", R, C);
+    const int slices = R >= 1024 ? 32 : (R >= 64 ? 8 : 1);
+    colsum_f32_kernel<<<dim3(ocn_cdiv(C, 64), slices), dim3(256), 0, (hipStream_t)stream>>>(x, out, R, C);
+    OCN_CHECK_LAUNCH("ocn_colsum_f32");
+    return OCN_OK;
+}
+
 extern "C" int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                                 const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db,
+                                 const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, float* dcol,
                                  int M, int C, ocn_stream_t stream) {
     OCN_CHECK_ARG(dy && x && w && mean && rstd && dw && db && (dx_f32 || dx_bf16), "ocn_layernorm_bwd: null operand");
     OCN_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "ocn_layernorm_bwd: bad shape M=%d C=%d", M, C);
     hipStream_t st = (hipStream_t)stream;
     bf16* dx16 = (bf16*)dx_bf16;
     switch (ocn_cdiv(C, 256)) {
-        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
-        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
-        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
-        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
-        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
-        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, M, C); break;
+        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
+        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
+        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
+        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
+        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
+        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
     }
     OCN_CHECK_LAUNCH("ocn_layernorm_bwd");
     return OCN_OK;

@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(const float* __res
     float ds = 0.f;
     for (int c = threadIdx.x; c < N; c += blockDim.x) {
         const float v = row[c];
-        const float g = (__expf(v - mx) * inv - (c == label ? 1.f : 0.f)) * grad_scale;
-        G[(size_t)r * ldg + c] = f2bf(g);
-        ds += g * v;
+        const float pr = __expf(v - mx) * inv;
+        G[(size_t)r * ldg + c] = f2bf(pr * grad_scale);  // softmax * grad_scale only: the caller applies -onehot * grad_scale exactly (see ocn_fused_logits_ce)
+        ds += (pr - (c == label ? 1.f : 0.f)) * grad_scale * v;
     }
     ds = block_sum(ds, red);
     if (threadIdx.x == 0) {
@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void siglip_rows_kernel(const float* __restric
         const float z = lab * v;
         const float e = __expf(-fabsf(z));
         ls += fmaxf(-z, 0.f) + log1pf(e);                             // -logsigmoid(z)
-        const float sig_neg = (z >= 0.f) ? e / (1.f + e) : 1.f / (1.f + e);  // sigmoid(-z)
-        const float g = -lab * sig_neg * grad_scale;
-        G[(size_t)r * ldg + c] = f2bf(g);
+        // d/dlogit = -lab * sigmoid(-z) = sigmoid(v) - [c == pos]: G holds sigmoid(v) * grad_scale ONLY, the caller applies the -[c == pos] * grad_scale
+        // part exactly in fp32 (as for the cross-entropy, ocn_fused_logits_ce: (sigmoid - 1) rounded to bf16 loses its sigmoid)
+        const float sig = (v >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);  // sigmoid(v); e = exp(-|v|) as |z| = |v|
+        const float g = (sig - (c == pos ? 1.f : 0.f)) * grad_scale;
+        G[(size_t)r * ldg + c] = f2bf(sig * grad_scale);
         ds += g * (v - bias);
         dbs += g;
     }
@@ -127,8 +129,10 @@ extern "C" int64_t ocn_fused_logits_ce_workspace_floats(int R, int N) { return (
 
 // Logits + cross-entropy without the logits: two passes of the persistent NT GEMM over X . Y^T whose epilogues consume the fp32
 // tile in registers -- pass 1 leaves per-row (max, sum exp) partials (one per 64-column strip) and the label logit, a small kernel
-// combines them into the row log-sum-exp and the loss, pass 2 recomputes the tile and writes G = (softmax - onehot) * grad_scale as
-// bf16 plus sum(G * logits).  4 * R * N * E flops instead of 2, and R * N * 2 bytes of HBM writes instead of R * N * (4 + 3 * 4 + 2).
+// combines them into the row log-sum-exp and the loss, pass 2 recomputes the tile and writes G = softmax * grad_scale as bf16 plus
+// sum((softmax - onehot) * grad_scale * logits).  The -onehot * grad_scale part of the logit gradient is NOT in G: the caller applies it
+// exactly in fp32 (dX_r -= grad_scale * Y[label_r], dY[label_r] -= grad_scale * X_r) -- in bf16 the label entry (p - 1) * grad_scale
+// rounds to -grad_scale, and the lost p is a common-mode bias that sums coherently over the batch.  4 * R * N * E flops instead of 2, and R * N * 2 bytes of HBM writes instead of R * N * (4 + 3 * 4 + 2).
 extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
                                    float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream) {
     OCN_CHECK_ARG(X && Y && G && workspace && loss_sum && dscale_sum, "ocn_fused_logits_ce: null operand");

@@ -81,7 +81,7 @@ class NativeGradSync:
         self.model, self.world_size, self.comm, self.pg = model, int(world_size), comm, process_group
         self.find_unused = bool(find_unused_parameters)
         self.enabled = True
-        self.stats = {"collectives": 0, "elements": 0, "ranges_per_group": []}
+        self.stats = {"collectives": 0, "elements": 0, "ranges_per_group": [], "order": []}
         self._stream = None
         self._groups, self._of = {}, {}
         for name, p in model.named_parameters():
@@ -109,6 +109,7 @@ class NativeGradSync:
             flat.mul_(1.0 / self.world_size)
         self.stats["collectives"] += 1
         self.stats["elements"] += flat.numel()
+        self.stats["order"] = (self.stats["order"] + [flat.numel()])[-256:]  # sizes of the last collectives, in issue order (must agree across ranks)
 
     def _allreduce_sum_small(self, t):
         if self.world_size == 1 and self.comm is None:
@@ -124,12 +125,12 @@ class NativeGradSync:
         import torch.distributed as dist
         with torch.no_grad():
             for t in list(self.model.parameters()) + list(self.model.buffers()):
-                if self.comm is not None:  # the C ABI has no broadcast: zero everywhere but on rank 0, then sum (fp32 / bf16 tensors)
+                if self.comm is not None:
+                    if t.dtype not in (torch.float32, torch.bfloat16):
+                        continue  # integer buffers (none in this model) are not parameters of the step
                     buf = t.data if t.is_contiguous() else t.data.contiguous()
-                    if self.comm.rank != 0:
-                        buf.zero_()
-                    self.comm.all_reduce_sum(buf)
-                    if buf is not t.data and buf.data_ptr() != t.data.data_ptr():
+                    self.comm.broadcast(buf, 0)
+                    if buf.data_ptr() != t.data.data_ptr():
                         t.data.copy_(buf)
                 else:
                     dist.broadcast(t.data, src=0, group=self.pg)

@@ -78,6 +78,7 @@ class _PairTerm:
         self.ldg = _round_up(self.N, 64)
         self.logits = None
         self._bias = None
+        self._onehot = None  # (label_offset, grad_scale) once softmax_ce has filled G
         self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
 
     def compute_logits(self, bias=None):
@@ -98,6 +99,8 @@ class _PairTerm:
         on GEMM-sized shapes the logits never exist in memory: two passes of the MFMA GEMM with cross-entropy epilogues
         (``ocn_fused_logits_ce``: online log-sum-exp, then G) -- at the row-sharded global loss of 8 GPUs ([4096, 32768] per matrix)
         that is 256 MiB of G written instead of 512 MiB of fp32 logits written and read three times besides."""
+        # both kernels leave G = softmax * grad_scale; the -onehot * grad_scale part of the logit gradient is applied in dX / dY below, exactly
+        self._onehot = (int(label_offset), float(grad_scale))
         if self._bias is None and USE_FUSED_CE and ops.fused_logits_ce_supported(self.R, self.N, self.xs16.shape[1]):
             ops.fused_logits_ce(self.xs16, self.y16, self.G, self.N, label_offset, loss_scale, grad_scale, acc[0:1], acc[1:2])
             return
@@ -105,6 +108,7 @@ class _PairTerm:
 
     def siglip(self, label_offset, negative_only, loss_scale, grad_scale, acc):
         """acc[0] += loss, acc[1] += sum(G * logits) (bias included: the caller subtracts bias * acc[2]), acc[2] += sum(G)"""
+        self._onehot = None if negative_only else (int(label_offset), float(grad_scale))  # G = sigmoid * grad_scale; the positives' -1 in dX / dY
         ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
                         acc[0:1], acc[1:2], acc[2:3])
 
@@ -112,7 +116,18 @@ class _PairTerm:
         """s * G @ Y  -> [R, E] fp32"""
         yt = _bf16_transposed(self.Y, self.ldg)
         out = torch.empty(self.R, self.E, dtype=F32, device=self.X.device)
-        return ops.gemm_nt(ops.EPI_F32, self.G, yt, out).mul_(self.s)
+        ops.gemm_nt(ops.EPI_F32, self.G, yt, out)
+        if self._onehot is not None:
+            # The label column of the logit gradient, (p - 1) * gs: its "p" is in G, its "-1" is applied here in fp32.  In bf16 (p - 1) * gs rounds
+            # to -gs: the lost p_label (~ 1 / N) is tiny per row but has the same sign in EVERY row, and the parameter gradients are sums over the
+            # batch in which everything else nearly cancels (batch 4096 against the fp32 reference: |sum_b error_b| / |sum_b gradient_b| of the
+            # text-feature gradient 0.235 -> 0.004, the error of every parameter gradient more than halved; profiles/r04_parity_report.txt).
+            # It is taken from the SAME bf16-rounded operand rows the GEMM multiplied: sum_i G_ij is ~ 0 for every column j as well, so the
+            # rounding errors of the operand rows cancel in a sum over the batch only if both parts of the gradient see the same rounded rows
+            # (with the exact rows the label part stops cancelling them: visible at batch 8, where nothing averages them out).
+            off, gs = self._onehot
+            out.sub_(self.y16[off:off + self.R, :self.E].float(), alpha=gs)
+        return out.mul_(self.s)
 
     def dY(self):
         """G^T @ (s X) -> [N, E] fp32"""
@@ -120,6 +135,9 @@ class _PairTerm:
         Ep = self.xs16.shape[1]
         out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
         ops.gemm_tn_accum(self.G[:, :Np], self.xs16, out)
+        if self._onehot is not None:
+            off, gs = self._onehot
+            out[off:off + self.R].sub_(self.xs16.float(), alpha=gs)  # xs16 = bf16(s X): the rows the G^T (s X) product multiplied
         return out[:self.N, :self.E]
 
 

@@ -36,6 +36,7 @@ class _WeightCache:
         self._d = {}
         self.pair_wgrad = True  # block backward: run the wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.deterministic = False  # weight / bias gradient GEMMs in their reproducible form (ocn_gemm_tn_accum_det)
+        self.single_query = True  # pooled last block (head_dim 64): K, V projection only + single-query attention (_pooled_block_forward)
         self._side = _StreamMap()  # wgrad side streams of this tower, one per (device, main stream)
         self.twin_stats = {"hit": 0, "miss": 0}  # how often a block's backward found the bf16 twin of its incoming gradient (tests assert it does)
 
@@ -78,7 +79,7 @@ class _WeightCache:
         """a copied model (EMA twin, base_task.py:171) has new parameter addresses: none of the cached operand copies could ever hit
         there, so the copy starts empty instead of duplicating every bf16 weight"""
         new = _WeightCache()
-        new.pair_wgrad, new.deterministic = self.pair_wgrad, self.deterministic
+        new.pair_wgrad, new.deterministic, new.single_query = self.pair_wgrad, self.deterministic, self.single_query
         return new
 
 
@@ -92,8 +93,16 @@ class _WeightCache:
 # ------------------------------------------------------------------------------------------------------
 # ------------------------------------------------------------------------------------------------------
 
-def _publish_twin(g32, g16):
+def _publish_twin(g32, g16, colsum=None):
+    """``colsum`` (fp32 [C], optional): the column sums of g32 taken in fp32 by the kernel that produced it (LayerNorm backward's ``dcol``) -- the
+    bias gradient of the linear whose output gradient g32 is (the consuming block's c_proj)"""
     g32._ocn_bf16_twin = (g16, g32._version)
+    g32._ocn_colsum = (colsum, g32._version) if colsum is not None else None
+
+
+def _take_colsum(g32):
+    cs = getattr(g32, "_ocn_colsum", None)
+    return cs[0] if (cs is not None and cs[1] == g32._version and cs[0].device == g32.device) else None
 
 
 def _take_twin(g32, cache=None):
@@ -235,10 +244,22 @@ class _BlockFn(torch.autograd.Function):
         M, C = x.shape
         Fd = wfc.shape[0]
         dy16 = _take_twin(dy, cache)
+        dy_colsum = _take_colsum(dy)
         dy = dy.contiguous()
         # one zeroed fp32 arena for all of the block's parameter gradients (wgrad kernels accumulate atomically)
         grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
+        # Bias gradients of c_proj and out_proj = column sums of dy resp. dxmid.  Both come out of a LayerNorm backward in fp32, and that kernel
+        # sums them there (``dcol``) before the values are rounded to the bf16 operand of the weight-gradient GEMM.  c_proj's arrives with dy
+        # (published by the kernel that produced it), out_proj's is taken by this block's own LN2 backward.  (Measured at batch 4096 against the
+        # fp32 GPU reference: the bias gradients' error does NOT move -- 5.1e-2 either way on the last text block: it is upstream bf16 noise of the
+        # summands amplified by the cancellation of a contrastive batch, not the rounding of the sum's operands.  Kept because it is the exact sum
+        # and one bias MFMA less per block; profiles/r04_parity_report.txt.)
+        if dy_colsum is not None:
+            dbproj.copy_(dy_colsum)
+        # scratch bias row of the paired wgrad launch (below): a local of this function, so that the caching allocator cannot hand its memory to
+        # another tensor while the launch on the SIDE stream is still adding into it (it dies after the streams have joined)
+        dbo_scratch = ops.empty((C,), F32, x)
 
         dev = x.device
         # a locked block (lock_image_tower / lock_text_tower with some groups left trainable above it) still has to pass the gradient
@@ -251,8 +272,8 @@ class _BlockFn(torch.autograd.Function):
         pair, det = cache.pair_wgrad, cache.deterministic
         with _Paired(dev, cache, pair) as side:
             if need_w:
-                side(ops.gemm_tn_accum, dy16, g, dwproj, dbproj, 1.0, det)
-            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True)
+                side(ops.gemm_tn_accum, dy16, g, dwproj, None if dy_colsum is not None else dbproj, 1.0, det)
+            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True, dcol=dbo)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev, cache, pair) as side:
@@ -262,12 +283,14 @@ class _BlockFn(torch.autograd.Function):
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev, cache, pair) as side:
             if need_w and det:
-                side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo, 1.0, True)
+                side(ops.gemm_tn_accum, dxmid16, a, dwo, None, 1.0, True)
                 side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv, 1.0, True)
             elif need_w:  # out-proj and QKV wgrads share their rows and their K = C: one launch (36 tiles, 7 M-splits instead of 28 + 9)
-                side(ops.gemm_tn_accum2, dxmid16, a, dwo, dbo, dqkv, h1, dwqkv, dbqkv)
-            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True)
-        _publish_twin(dx, dx16)
+                # (the paired launch takes both bias rows or neither: out_proj's, which LN2's backward has already summed in fp32, goes to a scratch row)
+                side(ops.gemm_tn_accum2, dxmid16, a, dwo, dbo_scratch, dqkv, h1, dwqkv, dbqkv)
+            dx_colsum = torch.zeros((C,), dtype=F32, device=dev)  # -> the previous block's c_proj bias gradient
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True, dcol=dx_colsum)
+        _publish_twin(dx, dx16, dx_colsum)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None, None)
@@ -283,22 +306,37 @@ class _BlockFn(torch.autograd.Function):
 # (tests/test_model_gpu.py::test_pooled_last_block_equals_full_block); ``model.pooled_last_block = False`` (a constructor argument, too) runs
 # the full block.  `rows` = absolute row of each sequence's pooled token (int32 [B]); the output is [B, C].
 # ------------------------------------------------------------------------------------------------------
+# Round 4: the attention itself is pruned the same way (head_dim 64; ``model.pooled_single_query = False`` keeps the round-3 form).  Only ONE
+# query per sequence is ever read, so Q is projected for the B pooled rows alone (K and V for every row: in_proj_weight[C:]), the attention is
+# the single-query kernel of csrc/attention_pooled.hip (2 L d flops per head instead of 4 L^2 d; dK / dV are rank-1 in every key row), the
+# dgrad below it contracts over 2C instead of 3C, and the pooled rows' share of LayerNorm-1's backward (the query path + the residual) is
+# evaluated on those B rows and enters the all-row LayerNorm backward as its residual-gradient input (LayerNorm's backward is linear in dy).
 def _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off=None, act=ops.EPI_BIAS_GELU):
     (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
     M, C = x.shape
-    h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
-    qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
     hd = C // heads
-    a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd, seq_off)
-    a_p = ops.gather_rows_bf16(a, rows, B, 0)  # [B, C]: from here on only the pooled rows
-    x_p = ops.gather_rows(x, rows, B, 0)
+    single = cache.single_query and hd == 64
+    h1, _, mean1, rstd1 = ops.layernorm_fwd(x, ln1w, ln1b)
+    x_p = ops.gather_rows(x, rows, B, 0)  # [B, C]: from here on only the pooled rows
+    if single:
+        w_n = cache.get(wqkv, "n")  # [3C, C] bf16, rows [Wq; Wk; Wv] (transformer.py:93-95)
+        kv = ops.gemm_nt(ops.EPI_BF16, h1, w_n[C:], ops.empty((M, 2 * C), BF16, x), bias=bqkv[C:])
+        h1_p, _, mean1_p, rstd1_p = ops.layernorm_fwd(x_p, ln1w, ln1b)  # the pooled rows of h1 (row-wise op: the same values)
+        q_p = ops.gemm_nt(ops.EPI_BF16, h1_p, w_n[:C], ops.empty((B, C), BF16, x), bias=bqkv[:C])
+        a_p, lse = ops.attn_pooled_fwd(q_p, kv, rows, B, L, heads, causal, hd ** -0.5, seq_off)
+        att = (kv, q_p, h1_p, mean1_p, rstd1_p)
+    else:
+        qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
+        a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd, seq_off)
+        a_p = ops.gather_rows_bf16(a, rows, B, 0)
+        att = (qkv, a)
     xmid_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a_p, cache.get(wo, "n"), ops.empty((B, C), F32, x), bias=bo, resid=x_p)
     h2_p, _, mean2, rstd2 = ops.layernorm_fwd(xmid_p, ln2w, ln2b)
     Fd = wfc.shape[0]
     f_p = ops.empty((B, Fd), torch.uint8, x)
     g_p = ops.gemm_nt(act, h2_p, cache.get(wfc, "n"), ops.empty((B, Fd), BF16, x), bias=bfc, aux=f_p)
     y_p = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g_p, cache.get(wproj, "n"), ops.empty((B, C), F32, x), bias=bproj, resid=xmid_p)
-    return y_p, (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p)
+    return y_p, (mean1, rstd1, h1, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p, x_p, *att)
 
 
 class _PooledBlockFn(torch.autograd.Function):
@@ -321,35 +359,59 @@ class _PooledBlockFn(torch.autograd.Function):
         x, p, rows = t[0], t[1:13], t[13]
         (ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wproj, bproj) = p
         saved = _pooled_block_forward(x, p, rows, cache, B, L, heads, causal, seq_off, act)[1] if recompute else t[14:]
-        (mean1, rstd1, h1, qkv, a, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p) = saved
+        (mean1, rstd1, h1, lse, a_p, xmid_p, mean2, rstd2, h2_p, f_p, g_p, x_p) = saved[:12]
+        att = saved[12:]
+        single = len(att) == 5  # (kv, q_p, h1_p, mean1_p, rstd1_p) of the single-query form, (qkv, a) otherwise
         M, C = x.shape
         Fd = wfc.shape[0]
+        hd = C // heads
         dy16 = _take_twin(dy_p, cache)
+        dy_colsum = _take_colsum(dy_p)
         dy_p = dy_p.contiguous()
         grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
         need_w = any(ctx.needs_input_grad[1:13])
-        # ---- MLP branch and out-projection: the B pooled rows ----
+        # ---- MLP branch and out-projection: the B pooled rows (the same arithmetic as the full block's, row for row) ----
+        if dy_colsum is not None:
+            dbproj.copy_(dy_colsum)
+        else:
+            ops.colsum_f32(dy_p, dbproj)
         df_p = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((B, Fd), BF16, x), aux=f_p)
         dh2_p = ops.gemm_nt(ops.EPI_BF16, df_p, cache.get(wfc, "t"), ops.empty((B, C), BF16, x))
-        dxmid_p, dxmid16_p = ops.layernorm_bwd(dh2_p, xmid_p, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy_p, want_f32=True, want_bf16=True)
-        da_p = ops.gemm_nt(ops.EPI_F32, dxmid16_p, cache.get(wo, "t"), ops.empty((B, C), F32, x))
+        dxmid_p, dxmid16_p = ops.layernorm_bwd(dh2_p, xmid_p, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy_p, want_f32=True, want_bf16=True, dcol=dbo)
         det = cache.deterministic
         if need_w:
-            ops.gemm_tn_accum(dy16, g_p, dwproj, dbproj, 1.0, det)
+            ops.gemm_tn_accum(dy16, g_p, dwproj, None, 1.0, det)
             ops.gemm_tn_accum(df_p, h2_p, dwfc, dbfc, 1.0, det)
-            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, dbo, 1.0, det)
-        # ---- attention and everything below it: every row (the pooled rows' queries read all keys / values) ----
-        da = torch.zeros((M, C), dtype=BF16, device=x.device)
-        ops.scatter_rows(da_p, rows, None, B, 0, da)
-        dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, (C // heads) ** -0.5, C // heads, seq_off)
-        dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
-        if need_w:
-            ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv, 1.0, det)
-        dres = torch.zeros((M, C), dtype=F32, device=x.device)  # the residual path x -> xmid carries gradient on the pooled rows only
-        ops.scatter_rows(dxmid_p, rows, dres, B, 0, None)
-        dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True)
-        _publish_twin(dx, dx16)
+            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, None, 1.0, det)
+        dres = torch.zeros((M, C), dtype=F32, device=x.device)  # what reaches x besides LayerNorm-1's all-row backward: nonzero on the pooled rows only
+        if single:
+            kv, q_p, h1_p, mean1_p, rstd1_p = att
+            w_t = cache.get(wqkv, "t")  # [C, 3C] bf16: columns [Wq^T | Wk^T | Wv^T]
+            da_p = ops.gemm_nt(ops.EPI_BF16, dxmid16_p, cache.get(wo, "t"), ops.empty((B, C), BF16, x))
+            dq_p, dkv = ops.attn_pooled_bwd(q_p, kv, a_p, da_p, lse, rows, B, L, heads, causal, hd ** -0.5, seq_off)
+            dh1 = ops.gemm_nt(ops.EPI_BF16, dkv, w_t[:, C:], ops.empty((M, C), BF16, x))       # every row: through K and V
+            dh1q_p = ops.gemm_nt(ops.EPI_F32, dq_p, w_t[:, :C], ops.empty((B, C), F32, x))     # the pooled rows: through their query
+            if need_w:
+                ops.gemm_tn_accum(dkv, h1, dwqkv[C:], dbqkv[C:], 1.0, det)
+                ops.gemm_tn_accum(dq_p, h1_p, dwqkv[:C], dbqkv[:C], 1.0, det)
+            # pooled rows: LayerNorm-1 backward of the query path + the residual x -> xmid, then scattered into the all-row residual input
+            dxp, _ = ops.layernorm_bwd(dh1q_p, x_p, ln1w, mean1_p, rstd1_p, dln1w, dln1b, dres=dxmid_p, want_f32=True, want_bf16=False)
+            ops.scatter_rows(dxp, rows, dres, B, 0, None)
+        else:
+            qkv, a = att
+            # ---- attention and everything below it: every row (the pooled rows' queries read all keys / values) ----
+            da_p = ops.gemm_nt(ops.EPI_F32, dxmid16_p, cache.get(wo, "t"), ops.empty((B, C), F32, x))
+            da = torch.zeros((M, C), dtype=BF16, device=x.device)
+            ops.scatter_rows(da_p, rows, None, B, 0, da)
+            dqkv = ops.attn_bwd(qkv, a, da, lse, B, L, heads, causal, hd ** -0.5, hd, seq_off)
+            dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
+            if need_w:
+                ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv, 1.0, det)
+            ops.scatter_rows(dxmid_p, rows, dres, B, 0, None)  # the residual path x -> xmid carries gradient on the pooled rows only
+        dx_colsum = torch.zeros((C,), dtype=F32, device=x.device)  # -> the previous block's c_proj bias gradient
+        dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True, dcol=dx_colsum)
+        _publish_twin(dx, dx16, dx_colsum)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None, None, None)
@@ -505,15 +567,17 @@ class _HeadFn(torch.autograd.Function):
         dfeat = ops.l2norm_bwd(dy, y, inv) if normalize else dy
         dfeat16 = ops.cast_bf16(dfeat)
         C, E = proj.shape
-        dp16 = ops.gemm_nt(ops.EPI_BF16, dfeat16, cache.get(proj, "n"), ops.empty((B, C), BF16, dy))
+        # fp32 into the LayerNorm backward (B rows: free): ln_post / ln_final's bias gradient is a column sum over the B pooled rows
+        dp32 = ops.gemm_nt(ops.EPI_F32, dfeat16, cache.get(proj, "n"), ops.empty((B, C), F32, dy))
         dproj = torch.zeros_like(proj)
         ops.gemm_tn_accum(p16, dfeat16, dproj, None, 1.0, cache.deterministic)
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
-        dpooled, _ = ops.layernorm_bwd(dp16, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
+        dcol = torch.zeros_like(lnw)  # column sums of dpooled = of dx (zero elsewhere): the last block's c_proj bias gradient, in fp32
+        dpooled, _ = ops.layernorm_bwd(dp32, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True, dcol=dcol)
         dx = torch.zeros(xshape, dtype=F32, device=dy.device)
         dx16 = torch.zeros(xshape, dtype=BF16, device=dy.device)  # bf16 twin for the last block's dgrad / wgrad GEMMs
         ops.scatter_rows(dpooled, idx, dx, B, L, dx16)
-        _publish_twin(dx, dx16)
+        _publish_twin(dx, dx16, dcol)
         return dx, dlnw, dlnb, dproj, None, None, None, None, None
 
 
@@ -816,6 +880,8 @@ class NativeCLIP(nn.Module):
         # the last block of each tower only where its output is read (see _PooledBlockFn); the image tower has its own switch
         # (``model.visual.pooled_last_block``)
         self.pooled_last_block = self.visual.pooled_last_block = bool(pooled_last_block)
+        # the pooled last block's attention as ONE query per sequence (K, V projection only; head_dim 64): see _pooled_block_forward
+        self.pooled_single_query = True
         self.deterministic = bool(deterministic)
         self.pair_wgrad = bool(pair_wgrad)  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
         self.init_parameters()
@@ -907,9 +973,11 @@ class NativeCLIP(nn.Module):
         """execution switches of the model onto the two towers' operand caches (which the autograd Functions carry)"""
         self._cache.pair_wgrad = self.visual._cache.pair_wgrad = self.pair_wgrad and not overlap
         self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
+        self._cache.single_query = self.visual._cache.single_query = bool(self.pooled_single_query)
 
     def encode_image(self, image, normalize: bool = False):
         self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
+        self.visual._cache.single_query = bool(self.pooled_single_query)
         return self.visual(image, normalize)
 
     def encode_text(self, text, normalize: bool = False, _pack=None):
@@ -917,6 +985,7 @@ class NativeCLIP(nn.Module):
         if L != self.context_length:
             raise RuntimeError(f"text length {L} != context_length {self.context_length}")
         self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
+        self._cache.single_query = bool(self.pooled_single_query)
         if self.pack_text:
             pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size, self.attn_buckets)).finish()
             x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)

@@ -149,16 +149,24 @@ def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False):
-    """(dx fp32 | None, dx bf16 | None); ``dres`` = the residual branch's fp32 gradient, added in; dw / db are accumulated into"""
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dcol=None):
+    """(dx fp32 | None, dx bf16 | None); ``dres`` = the residual branch's fp32 gradient, added in; dw / db are accumulated into;
+    ``dcol`` (fp32 [C], accumulated into): column sums of dx in fp32 = the bias gradient of the linear in front of this LayerNorm's input"""
     M, C = x.shape
     is32 = dy.dtype == F32
     dx32 = empty((M, C), F32, x) if want_f32 else None
     dx16 = empty((M, C), BF16, x) if want_bf16 else None
     _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
               _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"),
-              _chk(dw, F32, "dw"), _chk(db, F32, "db"), M, C, _stream())
+              _chk(dw, F32, "dw"), _chk(db, F32, "db"), _chk(dcol, F32, "dcol"), M, C, _stream())
     return dx32, dx16
+
+
+def colsum_f32(x, out):
+    """out[C] += column sums of x [R, C] (fp32)"""
+    R, C = x.shape
+    _lib.call("ocn_colsum_f32", _chk(x, F32, "x"), _chk(out, F32, "out"), R, C, _stream())
+    return out
 
 
 # ---- attention -------------------------------------------------------------------------------------------
@@ -219,6 +227,29 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, causal, scale, head_dim=64, seq_off=N
     _lib.call("ocn_attn_bwd_hd", _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
               _chk(dqkv, BF16, "dqkv"), _chk(delta, F32, "delta"), B, L, H, head_dim, int(causal), float(scale), _stream())
     return dqkv
+
+
+def attn_pooled_fwd(q, kv, rows, B, L, H, causal, scale, seq_off=None):
+    """single-query attention of a tower's last block (head_dim 64): q [B, C] = the pooled rows' queries, kv [M, 2C] = K | V of every row;
+    ``rows`` int32 [B] = absolute row of each sequence's pooled token; ``seq_off`` as in attn_fwd (packed rows).  -> out [B, C], lse [B*H]"""
+    C = H * 64
+    if q.shape != (B, C) or kv.shape[1] != 2 * C:
+        raise RuntimeError(f"attn_pooled_fwd: q {tuple(q.shape)} / kv {tuple(kv.shape)} do not match B={B}, H={H}, head_dim 64")
+    so = _chk(_layout(seq_off).seq_off, torch.int32, "seq_off") if seq_off is not None else 0
+    out = empty((B, C), BF16, q)
+    lse = empty((B * H,), F32, q)
+    _lib.call("ocn_attn_pooled_fwd", _chk(q, BF16, "q"), _chk(kv, BF16, "kv"), _chk(out, BF16, "out"), _chk(lse, F32, "lse"), so,
+              _chk(rows, torch.int32, "rows"), B, L, H, int(causal), float(scale), _stream())
+    return out, lse
+
+
+def attn_pooled_bwd(q, kv, out, dout, lse, rows, B, L, H, causal, scale, seq_off=None):
+    """-> dq [B, C] bf16, dkv [M, 2C] bf16 (every key row written)"""
+    so = _chk(_layout(seq_off).seq_off, torch.int32, "seq_off") if seq_off is not None else 0
+    dq, dkv = empty(q.shape, BF16, q), empty(kv.shape, BF16, kv)
+    _lib.call("ocn_attn_pooled_bwd", _chk(q, BF16, "q"), _chk(kv, BF16, "kv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
+              _chk(dq, BF16, "dq"), _chk(dkv, BF16, "dkv"), so, _chk(rows, torch.int32, "rows"), B, L, H, int(causal), float(scale), _stream())
+    return dq, dkv
 
 
 # ---- embeddings / pooling ----------------------------------------------------------------------------------

@@ -44,7 +44,8 @@ def step_reference(cfg, state, image, text, chunk=512):
             ((i * I.grad[r0:r1]).sum() + (t * T.grad[r0:r1]).sum()).backward()
         torch.cuda.synchronize()
         grads = {k.replace("/", "."): (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in model.p.items()}
-        outs = {"image_features": I.detach().clone(), "text_features": T.detach().clone(), "loss": loss.detach().clone()}
+        outs = {"image_features": I.detach().clone(), "text_features": T.detach().clone(), "loss": loss.detach().clone(),
+                "d_image_features": I.grad.detach().clone(), "d_text_features": T.grad.detach().clone()}
         del model
         torch.cuda.empty_cache()
         return outs, grads

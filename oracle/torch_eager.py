@@ -77,6 +77,25 @@ def clip_loss(i, t, s):
     return (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels)) / 2
 
 
+def amp_step_grads(cfg, state, image, text):
+    """features, loss and every parameter gradient of ONE step of the same eager operators under ``torch.amp.autocast(bf16)`` -- the reference's own
+    ``--precision amp_bf16`` policy (precision.py:6-17) on this GPU.  tests/test_bench_size_gpu.py measures it against the fp32 reference at the
+    bench's batch to show what that POLICY costs the 1-D gradients there (column sums over thousands of rows that cancel), next to the native
+    path's own error: a yardstick for the tolerance, never a checker."""
+    dev = image.device
+    model = EagerCLIP(cfg, state).to(dev).train()
+    with torch.amp.autocast("cuda", dtype=torch.bfloat16):
+        i, t, s = model(image, text)
+        loss = clip_loss(i, t, s)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k.replace("/", "."): p.grad.detach().float().clone() for k, p in model.p.items() if p.grad is not None}
+    outs = {"image_features": i.detach().float(), "text_features": t.detach().float(), "loss": loss.detach().float()}
+    del model
+    torch.cuda.empty_cache()
+    return outs, grads
+
+
 def time_step(cfg, state, batch, steps=5, warmup=2, lr=5e-4):
     """seconds per training step (forward under bf16 autocast, backward, AdamW, clamp) on ``batch`` (already on the device)"""
     dev = batch["image"].device

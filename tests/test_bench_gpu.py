@@ -81,3 +81,21 @@ def test_bench_native_allreduce_paths():
     acc = _bench(["--native-allreduce", "--accum-freq", "2"])
     ref = _bench(["--accum-freq", "2"])
     assert abs(acc["config"]["final_loss"] - ref["config"]["final_loss"]) < 3e-2
+
+
+def test_bench_world8_on_one_device():
+    """bench.py's N = 8 launch -- the node size of BASELINE config 3 and of the driver's scaling run -- as eight ranks on the ONE GPU of the test
+    box (gloo transport, OCN_BENCH_ONE_DEVICE=1; RCCL refuses more than one rank per device): local batch 4 per rank, the packed [B, 2E] feature
+    all-gather + row-sharded global ClipLoss + reduce-scatter backward, the gradient all-reduce under DistributedDataParallel and under the native
+    per-block all-reduce, the max-over-ranks timing and rank 0's single JSON line.  The loss after three optimizer steps must be the one of ONE
+    process on the concatenation of the eight ranks' batches.  (Collective correctness only: unmeasured on multi-GPU hardware.)"""
+    env = {"OCN_BENCH_ONE_DEVICE": "1"}
+    small = ["--local-batch", "4"]
+    one = _bench(small + ["--data-ranks", "8"])
+    ddp = _bench(small + ["--dist-backend", "gloo"], nproc=8, env=env)
+    nat = _bench(small + ["--dist-backend", "gloo", "--native-allreduce"], nproc=8, env=env)
+    for rec in (ddp, nat):
+        assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 32 and rec["config"]["parallelism"] == "dp8" and rec["scaling"] == "weak"
+        assert "row-sharded" in rec["config"]["workload"]
+        assert abs(rec["config"]["final_loss"] - one["config"]["final_loss"]) < 3e-2, (rec["config"]["final_loss"], one["config"]["final_loss"])
+    assert one["config"]["global_batch"] == 32

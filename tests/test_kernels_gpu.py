@@ -100,11 +100,14 @@ def test_probe_tr16_layout(dev):
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (400, 384, 192), (1000, 2304, 768), (77 * 8, 512, 2048), (37, 6, 64), (4096, 4096, 512),
-                                   (1300, 520, 128), (3000, 264, 256), (70000, 776, 384)])
+                                   (1300, 520, 128), (3000, 264, 256), (70000, 776, 384), (25444, 768, 512), (66000, 520, 256)])
 def test_gemm_nt_epilogues(dev, M, N, K):
-    """every epilogue against fp32 torch.  The last three shapes are for the persistent kernel's epilogue-operand prefetch (round 4): K = 128 is a
+    """every epilogue against fp32 torch.  Shapes 7-9 are for the persistent kernel's epilogue-operand prefetch (round 4): K = 128 is a
     tile of ONE K-tile pair (the prefetch is issued in a tile's first phase), K = 256 two pairs, N % 16 == 8 puts the end of a row inside a lane's
-    16-byte piece of the saved gelu', and 70000 x 776 gives every workgroup several tiles (the prefetch crosses tile boundaries)"""
+    16-byte piece of the saved gelu', and 70000 x 776 gives every workgroup several tiles (the prefetch crosses tile boundaries; K = 384 is six
+    K-tiles: no half-tile tail).  The last two are for the HALF-TILE tail round: 300 tiles = one round + 44 tail tiles split over 88 workgroups, the
+    ragged last tile row (100 of 256 rows) among them; 774 tiles = three rounds + 6 tail tiles, K = 256 = exactly one pass of the half tile's
+    four-K-tile loop"""
     from open_clip_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
     a = bf(torch.randn(M, K, generator=g)).to(dev)
@@ -325,6 +328,66 @@ def test_attention(dev, B, L, H, causal):
         check(tag + f" d{nm}", dqkv[:, i * C:(i + 1) * C], x.grad[:, i * C:(i + 1) * C], rel=2e-2)
 
 
+@pytest.mark.parametrize("mode", ["image_cls", "text_packed", "text_dense", "long"])
+def test_attention_pooled_single_query(dev, mode):
+    """ocn_attn_pooled_fwd / ocn_attn_pooled_bwd (csrc/attention_pooled.hip): ONE query per (sequence, head) -- the pooled row of a tower's last
+    block (transformer.py:829-831, :941-944) -- against fp32 torch softmax attention restricted to that query: image tower (query = row 0 of every
+    sequence, no mask), packed text rows (query = a sequence's last row, ragged lengths), dense causal text (query = the EOT row in the MIDDLE of a
+    padded sequence: keys behind it are masked and their dK / dV rows must come back as zeros), and a 257-token sequence (17 key chunks)"""
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(len(mode))
+    B, H = 6, 3
+    C = H * 64
+    if mode == "image_cls":
+        L, lens, causal = 50, [50] * B, False
+        starts = [b * L for b in range(B)]
+        rows = [b * L for b in range(B)]
+        seq_off = None
+    elif mode == "long":
+        L, lens, causal = 257, [257] * B, False
+        starts = [b * L for b in range(B)]
+        rows = [b * L for b in range(B)]
+        seq_off = None
+    elif mode == "text_packed":
+        L, lens, causal = 77, [77, 9, 33, 1, 64, 17], True
+        starts = [sum(lens[:b]) for b in range(B)]
+        rows = [starts[b] + lens[b] - 1 for b in range(B)]
+        seq_off = torch.tensor(starts + [sum(lens)], dtype=torch.int32, device=dev)
+    else:
+        L, lens, causal = 77, [77] * B, True
+        starts = [b * L for b in range(B)]
+        rows = [b * L + e for b, e in enumerate([76, 8, 40, 0, 63, 31])]
+        seq_off = None
+    M = sum(lens)
+    kv = bf(torch.randn(M, 2 * C, generator=g) * 1.5).to(dev)
+    q = bf(torch.randn(B, C, generator=g) * 1.5).to(dev)
+    dout = bf(torch.randn(B, C, generator=g)).to(dev)
+    rows_t = torch.tensor(rows, dtype=torch.int32, device=dev)
+    out, lse = ops.attn_pooled_fwd(q, kv, rows_t, B, L, H, causal, 0.125, seq_off)
+    dkv_nan = None
+    dq, dkv = ops.attn_pooled_bwd(q, kv, out, dout, lse, rows_t, B, L, H, causal, 0.125, seq_off)
+    qf, kvf = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    ref_out, ref_lse = [], []
+    for b in range(B):
+        end = rows[b] + 1 if causal else starts[b] + lens[b]
+        k = kvf[starts[b]:end, :C].reshape(-1, H, 64).permute(1, 0, 2)      # [H, n, 64]
+        v = kvf[starts[b]:end, C:].reshape(-1, H, 64).permute(1, 0, 2)
+        s = (k @ qf[b].reshape(H, 64, 1)).squeeze(-1) * 0.125               # [H, n]
+        ref_lse.append(torch.logsumexp(s, dim=-1))
+        ref_out.append((torch.softmax(s, dim=-1).unsqueeze(1) @ v).reshape(C))
+    ref_out, ref_lse = torch.stack(ref_out), torch.stack(ref_lse).reshape(-1)
+    ref_out.backward(dout.float())
+    tag = f"attn_pooled[{mode}]"
+    check(tag + " out", out, ref_out.detach(), rel=4e-3)
+    check(tag + " lse", lse, ref_lse.detach(), rel=1e-5)
+    check(tag + " dq", dq, qf.grad, rel=1e-2)
+    check(tag + " dkv", dkv, kvf.grad, rel=1e-2)
+    assert torch.isfinite(dkv.float()).all()
+    if mode == "text_dense":  # rows behind the pooled token: exact zeros, written by the kernel (dkv came from torch.empty)
+        for b in range(B):
+            assert float(dkv[rows[b] + 1:(b + 1) * L].float().abs().max() if rows[b] + 1 < (b + 1) * L else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("L,causal,packed", [(50, False, False), (77, True, False), (77, True, True), (100, False, False)])
 def test_attention_backward_padded_rows_stay_finite(dev, L, causal, packed):
     """padded rows of the head-resident kernels (the tail of a sequence's last 32-row block) must never reach a result.  Adversarial case:
@@ -518,7 +581,10 @@ def test_loss_row_kernels(dev, R, N, off):
     loss = 0.5 * torch.nn.functional.cross_entropy(lr, labels)
     loss.backward()
     check(f"ce_rows[{R}x{N}] loss", acc[0:1], loss.detach().reshape(1), rel=1e-5)
-    check(f"ce_rows[{R}x{N}] G", G[:, :N], lr.grad, rel=4e-3)
+    # G = softmax * grad_scale: the -onehot * grad_scale part of the gradient is the caller's (applied exactly, loss.py::_PairTerm.dX / dY)
+    g_soft = lr.grad.clone()
+    g_soft[torch.arange(R), labels] += 0.5 / R
+    check(f"ce_rows[{R}x{N}] G", G[:, :N], g_soft, rel=4e-3)
     check(f"ce_rows[{R}x{N}] dscale", acc[1:2], ((lr.grad * logits).sum() / s).reshape(1), rel=1e-4)
     for neg in (0, 1):
         G.zero_()
@@ -532,7 +598,10 @@ def test_loss_row_kernels(dev, R, N, off):
         loss = -torch.nn.functional.logsigmoid(lab * lr).sum() / R
         loss.backward()
         check(f"siglip_rows[{R}x{N},neg{neg}] loss", acc3[0:1], loss.detach().reshape(1), rel=1e-5)
-        check(f"siglip_rows[{R}x{N},neg{neg}] G", G[:, :N], lr.grad, rel=4e-3)
+        g_sig = lr.grad.clone()  # G = sigmoid * grad_scale: the positives' -grad_scale is the caller's (loss.py::_PairTerm.dX / dY)
+        if not neg:
+            g_sig[torch.arange(R), labels] += 1.0 / R
+        check(f"siglip_rows[{R}x{N},neg{neg}] G", G[:, :N], g_sig, rel=4e-3)
         check(f"siglip_rows[{R}x{N},neg{neg}] dscale", acc3[1:2], ((lr.grad * (logits - bias)).sum() / s).reshape(1), rel=1e-4)
         check(f"siglip_rows[{R}x{N},neg{neg}] dbias", acc3[2:3], lr.grad.sum().reshape(1), rel=1e-4)
 
@@ -625,8 +694,8 @@ def test_ops_fail_loudly_on_cpu_tensors(dev):
 @pytest.mark.parametrize("R,N,E,off", [(4096, 32768, 512, 3 * 4096), (4096, 4096, 512, 0), (300, 1000, 128, 256), (2048, 16384, 768, 2048)])
 def test_fused_logits_cross_entropy(dev, R, N, E, off):
     """ocn_fused_logits_ce (no materialised logits; the row-sharded global loss of config 3 is [4096 x 32768 x 512]) against fp32
-    torch on the same bf16 operands: loss within 1e-5 relative, G within one bf16 rounding of the fp32 value (+2e-3 of the largest
-    |G| in absolute terms: exp of a recomputed logit), sum(G * logits) within 2e-4 relative."""
+    torch on the same bf16 operands: loss within 1e-5 relative, G = softmax * grad_scale within one bf16 rounding of the fp32 value (+2e-3 of
+    the largest |G| in absolute terms: exp of a recomputed logit), sum((softmax - onehot) * grad_scale * logits) within 2e-4 relative."""
     from open_clip_amd import ops
     g = torch.Generator(device=dev).manual_seed(R + N)
     x = torch.nn.functional.normalize(torch.randn(R, E, device=dev, generator=g), dim=-1)
@@ -647,9 +716,10 @@ def test_fused_logits_cross_entropy(dev, R, N, E, off):
         lse = torch.logsumexp(lg, -1)
         loss_ref += float(((lse - lg[torch.arange(lg.shape[0]), lab]) * ls).sum())
         Gref = torch.softmax(lg, -1)
-        Gref[torch.arange(lg.shape[0]), lab] -= 1
-        Gref *= gs
-        ds_ref += float((Gref * lg).sum())
+        Gfull = Gref.clone()
+        Gfull[torch.arange(lg.shape[0]), lab] -= 1
+        ds_ref += float((Gfull * gs * lg).sum())  # sum((softmax - onehot) * grad_scale * logits): the whole gradient
+        Gref *= gs                                 # G itself holds softmax * grad_scale only (the onehot part is the caller's, exact)
         got = G[sl, :N].float()
         gmax = max(gmax, float(Gref.abs().max()))
         bad += int(((got - Gref).abs() > Gref.abs() * 2.0 ** -7 + 2e-3 * float(Gref.abs().max())).sum())

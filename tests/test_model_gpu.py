@@ -613,11 +613,16 @@ def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
         model.encode_text(bad, normalize=True)
 
 
+@pytest.mark.parametrize("single_query", [True, False], ids=["single_query", "all_queries"])
 @pytest.mark.parametrize("variant", ["packed", "dense_text", "recompute", "siglip"])
-def test_pooled_last_block_equals_full_block(variant):
+def test_pooled_last_block_equals_full_block(variant, single_query):
     """the last block of each tower evaluated only on the pooled rows behind its attention (model.py::_PooledBlockFn) against the full
-    block: the dropped rows reach neither the features nor any gradient, so features, loss and every gradient must agree up to fp32
-    summation order (the weight gradients of the last block sum over B rows instead of M, the rest of the graph is the same)"""
+    block: the dropped rows reach neither the features nor any gradient.  With every query through the attention kernel (round 3's form,
+    ``pooled_single_query = False``) features, loss and every gradient agree up to fp32 summation order (the weight gradients of the last block
+    sum over B rows instead of M, the rest of the graph is the same).  The single-query form (round 4: K, V projection only, one query per
+    sequence through csrc/attention_pooled.hip) evaluates the SAME attention row in fp32 where the tile kernel rounds P to bf16 in front of its
+    P.V product, so the block's bf16 attention output differs by a rounding here and there: agreement at the level of one bf16 rounding of
+    that tensor -- an order of magnitude inside the oracle tolerances -- instead of bit for bit."""
     cfg = get_model_config("ViT-B-32")
     siglip = variant == "siglip"
     state = init_state_dict(cfg, seed=9, perturb=True, siglip=siglip)
@@ -625,8 +630,9 @@ def test_pooled_last_block_equals_full_block(variant):
     res = {}
     for pooled in (True, False):
         model = _build(cfg, state, siglip=siglip)
-        assert model.pooled_last_block and model.visual.pooled_last_block, "the pooled last block must be the default"
+        assert model.pooled_last_block and model.visual.pooled_last_block and model.pooled_single_query, "the pooled single-query last block must be the default"
         model.pooled_last_block = model.visual.pooled_last_block = pooled
+        model.pooled_single_query = single_query
         if variant == "dense_text":
             model.pack_text = False
         if variant == "recompute":
@@ -637,6 +643,17 @@ def test_pooled_last_block_equals_full_block(variant):
     fi = float((o1["image_features"] - o0["image_features"]).abs().max())
     ft = float((o1["text_features"] - o0["text_features"]).abs().max())
     worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0)
-    _report(f"pooled vs full last block [{variant}] (ViT-B-32, B=24): features max |diff| {fi:.1e} / {ft:.1e}, loss {l1:.7f} vs {l0:.7f}; "
-            f"worst gradient rel_l2 = {worst[0]:.3e} ({worst[1]})")
-    assert fi <= 1e-6 and ft <= 1e-6 and abs(l1 - l0) <= 2e-6 * abs(l0) and worst[0] <= 2e-5, (fi, ft, l1, l0, worst)
+    _report(f"pooled vs full last block [{variant}, {'single query' if single_query else 'all queries'}] (ViT-B-32, B=24): features max |diff| {fi:.1e} / {ft:.1e}, "
+            f"loss {l1:.7f} vs {l0:.7f}; worst gradient rel_l2 = {worst[0]:.3e} ({worst[1]})")
+    if single_query:
+        # The attention row differs by one bf16 rounding here and there, and ANY perturbation of that size at the top of the towers moves the
+        # gradients below it by what the oracle tolerances allow for: the 1-D gradients are column sums over rows that nearly cancel (a contrastive
+        # batch at initialisation), the small-norm tensors likewise -- measured 2e-2 on visual.positional_embedding and 3e-2 on a LayerNorm bias ten
+        # blocks below from this ONE change.  So the comparison uses the tolerance classes of the oracle tests; the kernel itself is held to 4e-3 /
+        # 1e-2 against fp32 torch in tests/test_kernels_gpu.py::test_attention_pooled_single_query.
+        gmax = max(float(v.norm()) for v in g0.values())
+        fr = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)) / _grad_tol(float(g0[k].norm()), gmax, g0[k].ndim), k) for k in g0)
+        _report(f"pooled vs full last block [{variant}, single query]: worst gradient = {fr[0]:.2f} of its oracle tolerance class ({fr[1]})")
+        assert fi <= 4e-4 and ft <= 4e-4 and abs(l1 - l0) <= 2e-3 and fr[0] <= 1.0, (fi, ft, l1, l0, fr)
+    else:
+        assert fi <= 1e-6 and ft <= 1e-6 and abs(l1 - l0) <= 2e-6 * abs(l0) and worst[0] <= 2e-5, (fi, ft, l1, l0, worst)

@@ -10,6 +10,11 @@ nproc > $O/${TAG}_host.txt; free -g | head -2 >> $O/${TAG}_host.txt
 if has gemmtests; then
   timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_gemm_bench_shapes_gpu.py -q -k "gemm" --maxfail=12 2>&1 | tail -40 > $O/${TAG}_gemmtests.log; stamp gemmtests
 fi
+if has newtests; then
+  rm -f $O/parity_report.txt
+  timeout 1500 python -m pytest ${NEW_TESTS:-tests/test_bench_size_gpu.py} -q --maxfail=12 --durations=10 ${NEW_TESTS_K:+-k "$NEW_TESTS_K"} 2>&1 | tail -60 > $O/${TAG}_newtests.log
+  cp $O/parity_report.txt $O/${TAG}_newtests_parity_report.txt 2>/dev/null; stamp newtests
+fi
 if has tests; then
   rm -f $O/parity_report.txt
   timeout 1800 python -m pytest tests -m gpu -q --maxfail=12 --durations=15 2>&1 | tail -60 > $O/${TAG}_tests.log
@@ -30,7 +35,7 @@ fi
 if has abstep; then  # whole step: this tree against the round-3 library on the same box, alternating
   for i in 1 2; do
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_abstep_new.json
-    OCN_LIB_PATH=$OLD timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_abstep_r03.json
+    (cd $GRAFT_REPO_ROOT/_ab/r03tree && timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline --no-cpu-baseline --no-eager-baseline --no-dense-text-line 2>&1 | grep '^{' >> $O/${TAG}_abstep_r03.json)
   done; stamp abstep
 fi
 if has bench; then timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
