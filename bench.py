@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the plain PyTorch-ROCm eager step timed beside the native one (N=1)")
     ap.add_argument("--eager-batch", type=int, default=4096, help="batch of the eager baseline (the bench's own batch: like for like; halved on out-of-memory)")
-    ap.add_argument("--deterministic", action="store_true", help="weight / bias gradient GEMMs in their reproducible form (NativeCLIP(deterministic=True))")
+    ap.add_argument("--deterministic", action="store_true", help="the reproducible step (NativeCLIP(deterministic=True) + NativeClipLoss(deterministic=True)): no "
+                    "fp32 atomic in any gradient or loss sum -- bit-identical from run to run")
     ap.add_argument("--accum-freq", type=int, default=1, help="reference --accum-freq semantics (train.py:236-311): F micro-batches of "
                     "--local-batch per optimizer step (features cached under no_grad, every micro-batch re-run with gradient against the "
                     "concatenation) -> global batch = local_batch * F * N; --accum-freq 8 is the metric's gbs=32768 on ONE GPU")
@@ -99,7 +100,7 @@ def parse():
 
 
 NT_KERNEL = {0: "gemm_nt5_kernel<0,false,0> (plain bf16 out)", 1: "gemm_nt5_kernel<1,false,2> (bias + GELU, saves gelu' in 8 bits)",
-             2: "gemm_nt5_kernel<2,false,40> (bias + fp32 residual)", 3: "gemm_nt5_kernel<3,false,32> (x saved 8-bit gelu')",
+             2: "gemm_nt5_kernel<2,false,8> (bias + fp32 residual)", 3: "gemm_nt5_kernel<3,false,10> (x saved 8-bit gelu')",
              4: "gemm_nt5_kernel<4,false,0> (fp32 out)", 5: "gemm_nt5_kernel<5,false,0> (logits: CE statistics)",
              6: "gemm_nt5_kernel<6,false,0> (logits: CE gradient)"}
 
@@ -132,6 +133,8 @@ class GemmTimer:
                 return nt(epi, a, b, out, **kw)
             M, K, N = a.shape[0], a.shape[1], b.shape[0]
             name = "gemm_nt5_kernel<0,false,2> (bf16 out with N >= 1024, non-temporal stores: the QKV projections of ViT-B-32)" if (epi == 0 and N >= 1024) else NT_KERNEL.get(epi, f"gemm_nt epi {epi}")
+            if epi == 3 and N < 1024:
+                name = "gemm_nt5_kernel<3,false,8> (x saved 8-bit gelu', N < 1024)"
             nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (4.0 if epi in (2, 4) else 2.0)  # A, B once; the output
             nbytes += (4.0 * M * N if epi == 2 else 0.0) + (1.0 * M * N if epi in (1, 3) else 0.0)  # fp32 residual read; 8-bit gelu' written / read
             return timed("nt", name, 2.0 * M * N * K, nbytes, nt, epi, a, b, out, **kw)
@@ -356,10 +359,10 @@ def main():
     loss_comm = native_comm if (args.native_comm and world > 1) else None
     if args.siglip:
         from open_clip_amd.loss import NativeSigLipLoss
-        loss_fn = NativeSigLipLoss(rank=rank, world_size=world, comm=loss_comm)
+        loss_fn = NativeSigLipLoss(rank=rank, world_size=world, comm=loss_comm, deterministic=args.deterministic)
     else:
         loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
-                                 row_sharded=(world > 1 and not args.naive_global_loss), comm=loss_comm)
+                                 row_sharded=(world > 1 and not args.naive_global_loss), comm=loss_comm, deterministic=args.deterministic)
     opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=args.lr, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
     grad_sync = None

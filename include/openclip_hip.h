@@ -104,8 +104,11 @@ int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf
                       float* rstd, int M, int C, float eps, ocn_stream_t stream);
 int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                       const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, float* dcol,
-                      int M, int C, ocn_stream_t stream);
-int ocn_colsum_f32(const float* x, float* out, int R, int C, ocn_stream_t stream);
+                      float* det_workspace, int M, int C, ocn_stream_t stream);
+/* det_workspace (may be NULL = fp32 atomics): ocn_layernorm_bwd_det_workspace_floats(M, C) floats; the workgroups' partial dw / db / dcol rows go to
+ * their own slabs and a second kernel adds them in workgroup order: bit-reproducible from run to run (torch.use_deterministic_algorithms) */
+int64_t ocn_layernorm_bwd_det_workspace_floats(int M, int C);
+int ocn_colsum_f32(const float* x, float* out, int R, int C, int deterministic, ocn_stream_t stream);
 /* ---- attention core (transformer.py:199-244: head split + F.scaled_dot_product_attention) ------
  * qkv bf16 [B*L, 3*H*64] (q | k | v column blocks, heads contiguous inside each: the layout F.linear with
  * in_proj_weight produces, transformer.py:169); out bf16 [B*L, H*64]; lse fp32 [B*H*L] (natural log).
@@ -166,7 +169,7 @@ int ocn_patchify_u8(const void* image_u8, int hwc, const float* mean3, const flo
 int ocn_embed_assemble_fwd(const float* patch_out, const float* cls, const float* pos, float* emb, int B, int G, int C,
                            ocn_stream_t stream);
 int ocn_embed_assemble_bwd(const float* demb, void* dpatch_bf16, float* dpos, float* dcls, int B, int G, int C,
-                           ocn_stream_t stream);
+                           int deterministic, ocn_stream_t stream);
 
 /* ---- text tower embedding (model.py:399-401) ---------------------------------------------------
  * fwd: x[b,l,:] = table[text[b,l],:] + pos[l,:];  bwd: dtable[text[b,l],:] += dx[b,l,:] (fp32 atomics),
@@ -178,9 +181,12 @@ int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* dtable, flo
 
 /* The same backward from SORTED ids (no per-occurrence atomics): sorted_tokens = the B*L token ids in ascending order, order[i] = the flat
  * row (b*L + l) of dx that sorted_tokens[i] came from (any stable or unstable sort; torch.sort on the device).  dtable must arrive ZEROED
- * (complete runs are stored, not added); dpos is accumulated into.  dx is fp32 or (dx_is_bf16) bf16 [B*L, C]. */
+ * (complete runs are stored, not added); dpos is accumulated into.  dx is fp32 or (dx_is_bf16) bf16 [B*L, C].
+ * deterministic != 0 (here, in ocn_embed_assemble_bwd and in the packed form below): the reproducible form -- every run of equal ids is summed
+ * by ONE workgroup in sorted order (needs a STABLE sort), dpos / dcls by a single writer per element in batch order: no fp32 atomics, bit-identical
+ * from run to run (torch.use_deterministic_algorithms); long runs (SOT / EOT, the zero padding of a dense batch) serialise. */
 int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable, float* dpos,
-                               int B, int L, int C, int vocab, ocn_stream_t stream);
+                               int B, int L, int C, int vocab, int deterministic, ocn_stream_t stream);
 
 /* ---- packed text batches (see ocn_attn_fwd_varlen) -----------------------------------------------
  * seq_pack_plan: eot[b] = argmax(text[b,:]); seq_off = exclusive scan of (eot+1) (B+1 entries, seq_off[B] = packed row count M);
@@ -198,7 +204,7 @@ int ocn_seq_pack_rows(const int64_t* text, const int32_t* seq_off, int64_t* toke
 int ocn_token_embed_fwd_rows(const int64_t* tokens, const int32_t* posidx, const float* table, const float* pos, float* x, long M, int C,
                              int vocab, ocn_stream_t stream);
 int ocn_token_embed_bwd_sorted_varlen(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable,
-                                      float* dpos, const int32_t* seq_off, int B, int L, long M, int C, int vocab, ocn_stream_t stream);
+                                      float* dpos, const int32_t* seq_off, int B, int L, long M, int C, int vocab, int deterministic, ocn_stream_t stream);
 
 /* ---- pooling (transformer.py:786-787 'tok'; :941-944 'argmax') ---------------------------------
  * argmax_rows: idx[b] = first index of max(text[b,:]) (torch.argmax semantics)
@@ -209,6 +215,9 @@ int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L
 int ocn_gather_rows_bf16(const void* x, const int32_t* idx, void* out, int B, int L, int C, ocn_stream_t stream); /* bf16 x / out, C % 8 == 0 */
 int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
                      ocn_stream_t stream);
+/* dx[row_b] += d[b] (fp32), dx_bf16[row_b] = bf16 of the sum (may be NULL): the pooled rows' share of the last block's input gradient added
+ * into the all-row LayerNorm backward's result instead of travelling through a zero [M, C] residual-gradient matrix */
+int ocn_scatter_add_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C, ocn_stream_t stream);
 
 /* ---- F.normalize (model.py:391,411; eps 1e-12) -------------------------------------------------
  * fwd: y = x / max(||x||, eps) as fp32 and bf16, inv_norm[B] saved; bwd: dx = (dy - y*(y.dy)) * inv_norm */
@@ -227,8 +236,10 @@ int ocn_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float
  *   sigmoid(logits)*grad_scale (the positives' -grad_scale is the caller's, exact, as for the cross-entropy);
  *   dscale_sum += sum(g*grad_scale*(logits-bias))*inv_logit_scale; dbias_sum += sum(g*grad_scale). */
 int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, float loss_scale,
-                        float grad_scale, float inv_logit_scale, float* loss_sum, float* dscale_sum,
+                        float grad_scale, float inv_logit_scale, float* loss_sum, float* dscale_sum, float* det_rows,
                         ocn_stream_t stream);
+/* det_rows (may be NULL = fp32 atomics into the three sums): fp32 [R, 3]; row r's contributions to loss_sum / dscale_sum / dbias_sum are
+ * written there instead, for the caller to add up in a fixed order (ocn_colsum_f32(..., deterministic = 1)): the reproducible form */
 /* The same cross-entropy WITHOUT materialised logits (loss.py:103-110 + :136-139 for a [R, N] block of logits_per_image / _per_text;
  * the row-sharded global loss of 8 GPUs has R = 4096, N = 32768): X bf16 [R, E] (already times logit_scale), Y bf16 [N, E]; two passes
  * of the MFMA GEMM consume the fp32 logits tile in registers (online log-sum-exp, then G = softmax * grad_scale as bf16 [R, ldg]; the
@@ -239,7 +250,7 @@ int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, i
                         float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
 int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,
                     float bias, float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
-                    float* dscale_sum, float* dbias_sum, ocn_stream_t stream);
+                    float* dscale_sum, float* dbias_sum, float* det_rows, ocn_stream_t stream);
 
 /* ---- optimizer (train.py:181-182, image_text_task.py:91-101) --------------
  * sumsq: out[0] += sum(x^2) (grad-norm for clip_grad_norm_);

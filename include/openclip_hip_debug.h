@@ -17,8 +17,12 @@ extern "C" {
  *   bits 0..3  NT kernel: 0 auto, 4 the general 256x256 ring kernel, 5 the persistent 256x256 kernel (falls back to 4)
  *   bits 4..7  TN kernel: 0 auto, 1 the general 128x128 kernel, 3 the hand-scheduled 256x256 kernel (falls back to 1)
  *   bits 8..   developer knobs of the persistent NT kernel: (v >> 8) & 1 skip GELU arithmetic (results wrong), & 2 / & 8 flip the
- *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 64 timeline
- *              build; (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off) */
+ *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 32 / & 128 drop the
+ *              epilogue's stores / operand loads (results wrong), & 64 timeline build, & 0x200000 whole tail tiles instead of half tiles;
+ *              (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off).
+ *              The knobs of this group that live INSIDE the kernel exist in the developer build only (libopenclip_hip_dev.so:
+ *              python -m open_clip_amd.build --dev, -DOCN_DEV_BUILD; select it with OCN_LIB_PATH): the product library compiles none of
+ *              them and ignores these bits. */
 int ocn_set_gemm_variant(int nt_variant);
 /* developer knobs (process-global; experiments and A/B measurements of tools/sweep.py, never needed by a user):
  *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)

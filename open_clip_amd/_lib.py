@@ -23,8 +23,8 @@ SIGNATURES = {
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
     "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
-    "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "ocn_colsum_f32": [_p, _p, _i, _i, _p],
+    "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ocn_colsum_f32": [_p, _p, _i, _i, _i, _p],
     "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_fwd_hd": [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
@@ -36,25 +36,26 @@ SIGNATURES = {
     "ocn_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     "ocn_patchify_u8": [_p, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _p, _i, _i, _i, _i, _i, _p],
     "ocn_embed_assemble_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
-    "ocn_embed_assemble_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "ocn_embed_assemble_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ocn_token_embed_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ocn_token_embed_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "ocn_token_embed_bwd_sorted": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p],
+    "ocn_token_embed_bwd_sorted": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "ocn_seq_pack_plan": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_seq_pack_rows": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_token_range_check": [_p, _l, _i, _p, _p],
     "ocn_seq_bucket_plan": [_p, _p, _p, _i, _i, _p],
     "ocn_token_embed_fwd_rows": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
-    "ocn_token_embed_bwd_sorted_varlen": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _p],
+    "ocn_token_embed_bwd_sorted_varlen": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],
     "ocn_gather_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ocn_gather_rows_bf16": [_p, _p, _p, _i, _i, _i, _p],
     "ocn_scatter_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "ocn_scatter_add_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_l2norm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ocn_l2norm_bwd": [_p, _p, _p, _p, _i, _i, _p],
-    "ocn_softmax_ce_rows": [_p, _i, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p],
+    "ocn_softmax_ce_rows": [_p, _i, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p],
     "ocn_fused_logits_ce": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p, _p, _p, _p],
-    "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p],
+    "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p],
     "ocn_sumsq_accum": [_p, _l, _p, _p],
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
     "ocn_adamw_multi": [_p, _p, _i, _f, _f, _f, _p, _f, _p],
@@ -80,7 +81,7 @@ DEBUG_SIGNATURES = {
     "ocn_debug_stream_with_cu_mask": [_p, _i, _p],
 }
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_det_workspace_bytes": ([_i, _i, _i], _l),
-            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l)}
+            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l)}
 
 _lib = None
 _lock = threading.Lock()

@@ -202,7 +202,7 @@ OCN_DEV f32x4 load4f<bf16>(const bf16* p) {
 template <typename T>
 __global__ __launch_bounds__(128) void token_embed_bwd_sorted_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__ order,
                                                                      const T* __restrict__ dx, float* __restrict__ dtable, long n, int C,
-                                                                     int vocab, int CH) {
+                                                                     int vocab, int CH, int det) {
     const long i0 = (long)blockIdx.x * CH, i1 = min(n, i0 + CH);
     // a run is identified by the CLAMPED id (ids outside the vocabulary share row 0 / vocab - 1), so whether a run continues into the
     // neighbouring chunk is decided on clamped ids too: two chunks must never both take one row for a complete run and plain-store it
@@ -210,6 +210,26 @@ __global__ __launch_bounds__(128) void token_embed_bwd_sorted_kernel(const int64
         const long t = keys[i];
         return t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
     };
+    if (det) {
+        // reproducible form (NativeCLIP(deterministic=True)): a run of equal ids is summed by ONE workgroup -- the one whose chunk holds the run's
+        // first entry walks it to its end, wherever that is, in sorted (stable) order, and plain-stores the row; a chunk that begins inside a run
+        // skips it.  No atomics; long runs (SOT / EOT: B entries; the zero padding of a dense batch) serialise on one workgroup.
+        for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+            long i = i0;
+            if (i0 > 0) {
+                const long t0 = clamped(i0);
+                if (clamped(i0 - 1) == t0)
+                    while (i < n && clamped(i) == t0) ++i;
+            }
+            while (i < i1) {
+                const long tok = clamped(i);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (; i < n && clamped(i) == tok; ++i) acc += load4f<T>(dx + (size_t)order[i] * C + c);
+                *(f32x4*)(dtable + (size_t)tok * C + c) = acc;
+            }
+        }
+        return;
+    }
     for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         long cur = -1, seg_start = i0;
@@ -392,6 +412,25 @@ __global__ void scatter_rows_kernel(const float* __restrict__ d, const int32_t* 
     }
 }
 
+// dx[row_b] += d[b]; dx16[row_b] = bf16 of the sum: the pooled rows' share of a gradient added into the all-row result (rows are distinct)
+__global__ void scatter_add_rows_kernel(const float* __restrict__ d, const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                        bf16* __restrict__ dx16, int B, int L, int C) {
+    const int c4n = C / 4;
+    const long total = (long)B * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long b = i / c4n;
+        const int t = idx ? idx[b] : 0;
+        const size_t o = ((size_t)b * L + t) * C + c;
+        const f32x4 v = *(const f32x4*)(d + (size_t)b * C + c) + *(const f32x4*)(dx + o);
+        *(f32x4*)(dx + o) = v;
+        if (dx16) {
+            bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)(dx16 + o) = o4;
+        }
+    }
+}
+
 // ---- F.normalize ---------------------------------------------------------------------------------------
 __global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, bf16* __restrict__ y16,
                                   float* __restrict__ inv_norm, int B, int E, float eps) {
@@ -487,11 +526,11 @@ extern "C" int ocn_embed_assemble_fwd(const float* patch_out, const float* cls, 
     return OCN_OK;
 }
 
-extern "C" int ocn_embed_assemble_bwd(const float* demb, void* dpatch_bf16, float* dpos, float* dcls, int B, int G, int C,
+extern "C" int ocn_embed_assemble_bwd(const float* demb, void* dpatch_bf16, float* dpos, float* dcls, int B, int G, int C, int deterministic,
                                       ocn_stream_t stream) {
     OCN_CHECK_ARG(demb && dpatch_bf16 && dpos && dcls, "ocn_embed_assemble_bwd: null operand");
     OCN_CHECK_ARG(B > 0 && G > 0 && C % 4 == 0, "ocn_embed_assemble_bwd: bad shape");
-    const int bchunk = 32;
+    const int bchunk = deterministic ? B : 32;  // deterministic: ONE batch chunk -- every element of dpos / dcls has a single writer summing in batch order
     dim3 grid(ocn_cdiv((long)(G + 1) * (C / 4), 256), ocn_cdiv(B, bchunk));
     hipLaunchKernelGGL(embed_assemble_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, demb, (bf16*)dpatch_bf16, dpos, dcls, B, G, C, bchunk);
     OCN_CHECK_LAUNCH("ocn_embed_assemble_bwd");
@@ -520,19 +559,19 @@ extern "C" int ocn_token_embed_bwd(const int64_t* text, const float* dx, float* 
 }
 
 extern "C" int ocn_token_embed_bwd_sorted(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable, float* dpos,
-                                          int B, int L, int C, int vocab, ocn_stream_t stream) {
+                                          int B, int L, int C, int vocab, int deterministic, ocn_stream_t stream) {
     OCN_CHECK_ARG(sorted_tokens && order && dx && dtable && dpos, "ocn_token_embed_bwd_sorted: null operand");
     OCN_CHECK_ARG(B > 0 && L > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_bwd_sorted: bad shape");
     OCN_CHECK_ARG(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dtable & 15) == 0, "ocn_token_embed_bwd_sorted: operands must be 16-byte aligned");
     const long n = (long)B * L;
-    const int CH = 64, bchunk = 128;
+    const int CH = 64, bchunk = deterministic ? B : 128;  // deterministic: one batch chunk (a single writer per element of dpos) and whole runs per workgroup
     const dim3 g1((unsigned)ocn_cdiv(n, CH)), g2(ocn_cdiv((long)L * (C / 4), 256), ocn_cdiv(B, bchunk));
     hipStream_t st = (hipStream_t)stream;
     if (dx_is_bf16) {
-        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<bf16>, g1, dim3(128), 0, st, sorted_tokens, order, (const bf16*)dx, dtable, n, C, vocab, CH);
+        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<bf16>, g1, dim3(128), 0, st, sorted_tokens, order, (const bf16*)dx, dtable, n, C, vocab, CH, deterministic);
         hipLaunchKernelGGL(pos_grad_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dx, dpos, B, L, C, bchunk);
     } else {
-        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<float>, g1, dim3(128), 0, st, sorted_tokens, order, (const float*)dx, dtable, n, C, vocab, CH);
+        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<float>, g1, dim3(128), 0, st, sorted_tokens, order, (const float*)dx, dtable, n, C, vocab, CH, deterministic);
         hipLaunchKernelGGL(pos_grad_kernel<float>, g2, dim3(256), 0, st, (const float*)dx, dpos, B, L, C, bchunk);
     }
     OCN_CHECK_LAUNCH("ocn_token_embed_bwd_sorted");
@@ -624,18 +663,19 @@ extern "C" int ocn_token_embed_fwd_rows(const int64_t* tokens, const int32_t* po
 }
 
 extern "C" int ocn_token_embed_bwd_sorted_varlen(const int64_t* sorted_tokens, const int64_t* order, const void* dx, int dx_is_bf16, float* dtable,
-                                                 float* dpos, const int32_t* seq_off, int B, int L, long M, int C, int vocab, ocn_stream_t stream) {
+                                                 float* dpos, const int32_t* seq_off, int B, int L, long M, int C, int vocab, int deterministic,
+                                                 ocn_stream_t stream) {
     OCN_CHECK_ARG(sorted_tokens && order && dx && dtable && dpos && seq_off, "ocn_token_embed_bwd_sorted_varlen: null operand");
     OCN_CHECK_ARG(B > 0 && L > 0 && M > 0 && C % 4 == 0 && vocab > 0, "ocn_token_embed_bwd_sorted_varlen: bad shape");
     OCN_CHECK_ARG(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dtable & 15) == 0, "ocn_token_embed_bwd_sorted_varlen: operands must be 16-byte aligned");
-    const int CH = 64, bchunk = 128;
+    const int CH = 64, bchunk = deterministic ? B : 128;
     const dim3 g1((unsigned)ocn_cdiv(M, CH)), g2(ocn_cdiv((long)L * (C / 4), 256), ocn_cdiv(B, bchunk));
     hipStream_t st = (hipStream_t)stream;
     if (dx_is_bf16) {
-        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<bf16>, g1, dim3(128), 0, st, sorted_tokens, order, (const bf16*)dx, dtable, M, C, vocab, CH);
+        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<bf16>, g1, dim3(128), 0, st, sorted_tokens, order, (const bf16*)dx, dtable, M, C, vocab, CH, deterministic);
         hipLaunchKernelGGL(pos_grad_varlen_kernel<bf16>, g2, dim3(256), 0, st, (const bf16*)dx, dpos, seq_off, B, L, C, bchunk);
     } else {
-        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<float>, g1, dim3(128), 0, st, sorted_tokens, order, (const float*)dx, dtable, M, C, vocab, CH);
+        hipLaunchKernelGGL(token_embed_bwd_sorted_kernel<float>, g1, dim3(128), 0, st, sorted_tokens, order, (const float*)dx, dtable, M, C, vocab, CH, deterministic);
         hipLaunchKernelGGL(pos_grad_varlen_kernel<float>, g2, dim3(256), 0, st, (const float*)dx, dpos, seq_off, B, L, C, bchunk);
     }
     OCN_CHECK_LAUNCH("ocn_token_embed_bwd_sorted_varlen");
@@ -681,6 +721,13 @@ extern "C" int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, v
     OCN_CHECK_ARG(d && (dx || dx_bf16) && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_scatter_rows: bad arguments");
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, d, idx, dx, (bf16*)dx_bf16, B, L, C);
     OCN_CHECK_LAUNCH("ocn_scatter_rows");
+    return OCN_OK;
+}
+
+extern "C" int ocn_scatter_add_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C, ocn_stream_t stream) {
+    OCN_CHECK_ARG(d && dx && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_scatter_add_rows: bad arguments");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, d, idx, dx, (bf16*)dx_bf16, B, L, C);
+    OCN_CHECK_LAUNCH("ocn_scatter_add_rows");
     return OCN_OK;
 }
 

@@ -722,6 +722,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 #define HDMA_A(SLOT) { const unsigned so_ = (ka < k_end ? ka : k_last) + hoff; DMA(dA0, voA, so_, SLOT, 0) DMA(dA0, voA, so_, SLOT, 1) ka += 128; }
 #define HDMA_B(P) { const unsigned so_ = kb < k_end ? kb : k_last; DMA(dB, voB, so_, B_SLOT(0, P), 0) DMA(dB, voB, so_, B_SLOT(0, P), 1) \
                     DMA(dB, voB, so_ + b_half, B_SLOT(1, P), 0) DMA(dB, voB, so_ + b_half, B_SLOT(1, P), 1) kb += 128; }
+            // the six pieces of a K-tile's refill, one at a time between MFMAs (B pieces first: the wait counts below rely on that order)
+#define HPIECE(N, P, SLOT)                                                                                               \
+    {                                                                                                                    \
+        if ((N) < 4) { const unsigned so_ = (kb < k_end ? kb : k_last) + (((N) & 2) ? b_half : 0u); DMA(dB, voB, so_, B_SLOT(((N) >> 1) & 1, P), (N) & 1) } \
+        else { const unsigned so_ = (ka < k_end ? ka : k_last) + hoff; DMA(dA0, voA, so_, SLOT, (N) & 1) }              \
+    }
             HDMA_A(A_SLOT(0, 0)) HDMA_B(0) HDMA_A(A_SLOT(0, 1)) HDMA_B(1) HDMA_A(A_SLOT(1, 0)) HDMA_A(A_SLOT(1, 1))
 #pragma unroll
             for (int y = 0; y < 2; ++y)
@@ -755,17 +761,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                \
         __builtin_amdgcn_s_barrier();                                                                   \
         SB();                                                                                           \
-        HDMA_B((Q) & 1)                                                                                 \
-        HDMA_A(A_SLOT((Q) >> 1, (Q) & 1))                                                               \
         RD_A(fa[0], 0, (((Q) + 1) & 3) >> 1, ((Q) + 1) & 1) RD_B(0, ((Q) + 1) & 1)                      \
         SB();                                                                                           \
-        MM(0, fa[1], 3)                                                                                 \
+        acc[0][0][0] = mfma32(fb[0][3], fa[1][0], acc[0][0][0]);                                        \
+        HPIECE(0, (Q) & 1, 0) HPIECE(1, (Q) & 1, 0)                                                     \
+        acc[0][0][1] = mfma32(fb[1][3], fa[1][0], acc[0][0][1]);                                        \
+        HPIECE(2, (Q) & 1, 0) HPIECE(3, (Q) & 1, 0)                                                     \
+        acc[0][1][0] = mfma32(fb[0][3], fa[1][1], acc[0][1][0]);                                        \
+        HPIECE(4, 0, A_SLOT((Q) >> 1, (Q) & 1)) HPIECE(5, 0, A_SLOT((Q) >> 1, (Q) & 1))                  \
+        acc[0][1][1] = mfma32(fb[1][3], fa[1][1], acc[0][1][1]);                                        \
+        kb += 128; ka += 128;                                                                           \
         SB(); LGKM0(); SB();                                                                            \
     }
             for (int kt = 0; kt < nk; kt += 4) { HKT(0) HKT(1) HKT(2) HKT(3) }
 #undef HKT
 #undef HDMA_A
 #undef HDMA_B
+#undef HPIECE
             epi_prefetch<EPI, AUX>(a, m0, n0, wm * 128 + h * 64, wn, lane, pf);
             epilogue5<EPI, AUX>(a, acc, m0, n0, wm, wn, lane, stg, pf, 1, h * 64);
         }

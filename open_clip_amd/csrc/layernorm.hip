@@ -87,7 +87,8 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
                                                       const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
                                                       float* __restrict__ dx32, bf16* __restrict__ dx16,
-                                                      float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dcol, int M, int C) {
+                                                      float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dcol,
+                                                      float* __restrict__ det_ws, int M, int C) {
     constexpr int BW = ln_bwd_waves<NV>();
     constexpr int NS = CS ? 3 : 2;  // sums per column: dgamma, dbeta (, dx)
     __shared__ float red[(BW + 1) / 2][NV * 256 * NS];
@@ -185,19 +186,45 @@ __global__ __launch_bounds__(ln_bwd_waves<NV>() * 64) void ln_bwd_kernel(const v
         __syncthreads();
     }
     if (wave == 0) {
+        // det_ws (NativeCLIP(deterministic=True)): this workgroup's partial rows go to its own slab [gridDim.x][3][C]; ln_bwd_finish_kernel adds the
+        // slabs up in workgroup order -- no two runs can differ in the order of the fp32 additions
+        float* slab = det_ws ? det_ws + (size_t)blockIdx.x * 3 * C : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (c < C) {
-                    unsafeAtomicAdd(dw + c + e, aw[i][e]);
-                    unsafeAtomicAdd(db + c + e, ab[i][e]);
-                    if (CS) unsafeAtomicAdd(dcol + c + e, ac[i][e]);
+                    if (slab) {
+                        slab[c + e] = aw[i][e];
+                        slab[C + c + e] = ab[i][e];
+                        slab[2 * C + c + e] = CS ? ac[CS ? i : 0][e] : 0.f;
+                    } else {
+                        unsafeAtomicAdd(dw + c + e, aw[i][e]);
+                        unsafeAtomicAdd(db + c + e, ab[i][e]);
+                        if (CS) unsafeAtomicAdd(dcol + c + e, ac[i][e]);
+                    }
                 }
             }
         }
     }
+}
+
+// second stage of the reproducible form: column c of dw / db / dcol += the G workgroups' partials, added in workgroup order by ONE thread
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ ws, int G, int C, float* __restrict__ dw, float* __restrict__ db,
+                                                            float* __restrict__ dcol) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float* slab = ws + (size_t)g * 3 * C;
+        a += slab[c];
+        b += slab[C + c];
+        d += slab[2 * C + c];
+    }
+    dw[c] += a;
+    db[c] += b;
+    if (dcol) dcol[c] += d;
 }
 
 int ln_grid(int M) {
@@ -230,17 +257,19 @@ void launch_fwd(hipStream_t st, const float* x, const float* w, const float* b, 
 }
 template <int NV, bool DY32, bool NT, bool CS>
 void launch_bwd4(hipStream_t st, const void* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* dres, float* dx32,
-                 bf16* dx16, float* dw, float* db, float* dcol, int M, int C) {
-    ln_bwd_kernel<NV, DY32, NT, CS><<<dim3(ln_bwd_grid<NV>(M)), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, M, C);
+                 bf16* dx16, float* dw, float* db, float* dcol, float* det_ws, int M, int C) {
+    const int G = ln_bwd_grid<NV>(M);
+    ln_bwd_kernel<NV, DY32, NT, CS><<<dim3(G), dim3(ln_bwd_waves<NV>() * 64), 0, st>>>(dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, det_ws, M, C);
+    if (det_ws) ln_bwd_finish_kernel<<<dim3(ocn_cdiv(C, 256)), dim3(256), 0, st>>>(det_ws, G, C, dw, db, dcol);
 }
 template <int NV>
 void launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, float* dcol, int M, int C) {
+                const float* rstd, const float* dres, float* dx32, bf16* dx16, float* dw, float* db, float* dcol, float* det_ws, int M, int C) {
     const bool nt = g_ocn_tuning[8] != 1;  // developer knob 8 = 1: default cache policy everywhere
 #define OCN_LN_BWD(DY32, NT)                                                                                                  \
     {                                                                                                                         \
-        if (dcol) launch_bwd4<NV, DY32, NT, true>(st, dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, M, C);             \
-        else launch_bwd4<NV, DY32, NT, false>(st, dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, M, C);                 \
+        if (dcol) launch_bwd4<NV, DY32, NT, true>(st, dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, det_ws, M, C);     \
+        else launch_bwd4<NV, DY32, NT, false>(st, dy, x, w, mean, rstd, dres, dx32, dx16, dw, db, dcol, det_ws, M, C);         \
     }
     if (dy_is_f32) {
         if (nt) OCN_LN_BWD(true, true) else OCN_LN_BWD(true, false)
@@ -282,9 +311,24 @@ extern "C" int ocn_layernorm_fwd(const float* x, const float* w, const float* b,
     return OCN_OK;
 }
 
-extern "C" int ocn_colsum_f32(const float* x, float* out, int R, int C, ocn_stream_t stream) {
+// floats of workspace the reproducible form of ocn_layernorm_bwd needs: one [3][C] slab per workgroup of its grid
+extern "C" int64_t ocn_layernorm_bwd_det_workspace_floats(int M, int C) {
+    int g = 0;
+    switch (ocn_cdiv(C, 256)) {
+        case 1: g = ln_bwd_grid<1>(M); break;
+        case 2: g = ln_bwd_grid<2>(M); break;
+        case 3: g = ln_bwd_grid<3>(M); break;
+        case 4: g = ln_bwd_grid<4>(M); break;
+        case 5: g = ln_bwd_grid<5>(M); break;
+        default: g = ln_bwd_grid<8>(M); break;
+    }
+    return (int64_t)g * 3 * C;
+}
+
+extern "C" int ocn_colsum_f32(const float* x, float* out, int R, int C, int deterministic, ocn_stream_t stream) {
     OCN_CHECK_ARG(x && out && R > 0 && C > 0, "ocn_colsum_f32: bad operand (R=%d C=%d)", R, C);
-    const int slices = R >= 1024 ? 32 : (R >= 64 ? 8 : 1);
+    // deterministic: ONE row slice -- a column is summed by four threads over fixed row subsets and folded in a fixed order: no atomic ever meets another
+    const int slices = deterministic ? 1 : (R >= 1024 ? 32 : (R >= 64 ? 8 : 1));
     colsum_f32_kernel<<<dim3(ocn_cdiv(C, 64), slices), dim3(256), 0, (hipStream_t)stream>>>(x, out, R, C);
     OCN_CHECK_LAUNCH("ocn_colsum_f32");
     return OCN_OK;
@@ -292,18 +336,18 @@ extern "C" int ocn_colsum_f32(const float* x, float* out, int R, int C, ocn_stre
 
 extern "C" int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
                                  const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, float* dcol,
-                                 int M, int C, ocn_stream_t stream) {
+                                 float* det_workspace, int M, int C, ocn_stream_t stream) {
     OCN_CHECK_ARG(dy && x && w && mean && rstd && dw && db && (dx_f32 || dx_bf16), "ocn_layernorm_bwd: null operand");
     OCN_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "ocn_layernorm_bwd: bad shape M=%d C=%d", M, C);
     hipStream_t st = (hipStream_t)stream;
     bf16* dx16 = (bf16*)dx_bf16;
     switch (ocn_cdiv(C, 256)) {
-        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
-        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
-        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
-        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
-        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
-        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, M, C); break;
+        case 1: launch_bwd<1>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, det_workspace, M, C); break;
+        case 2: launch_bwd<2>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, det_workspace, M, C); break;
+        case 3: launch_bwd<3>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, det_workspace, M, C); break;
+        case 4: launch_bwd<4>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, det_workspace, M, C); break;
+        case 5: launch_bwd<5>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, det_workspace, M, C); break;
+        default: launch_bwd<8>(st, dy, dy_is_f32, x, w, mean, rstd, dres, dx_f32, dx16, dw, db, dcol, det_workspace, M, C); break;
     }
     OCN_CHECK_LAUNCH("ocn_layernorm_bwd");
     return OCN_OK;

@@ -32,7 +32,7 @@ OCN_DEV float block_max(float v, float* red) {
 __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(const float* __restrict__ logits, int ld, bf16* __restrict__ G,
                                                                int ldg, int R, int N, int label_offset, float loss_scale,
                                                                float grad_scale, float inv_logit_scale,
-                                                               float* __restrict__ loss_sum, float* __restrict__ dscale_sum) {
+                                                               float* __restrict__ loss_sum, float* __restrict__ dscale_sum, float* __restrict__ det_rows) {
     __shared__ float red[8];
     const int r = blockIdx.x;
     const float* row = logits + (size_t)r * ld;
@@ -54,8 +54,14 @@ __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(const float* __res
     }
     ds = block_sum(ds, red);
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(loss_sum, (lse - row[label]) * loss_scale);
-        unsafeAtomicAdd(dscale_sum, ds * inv_logit_scale);
+        if (det_rows) {  // reproducible form: the row's contributions go to det_rows[r][0..2]; the caller adds the rows up in a fixed order
+            det_rows[(size_t)r * 3] = (lse - row[label]) * loss_scale;
+            det_rows[(size_t)r * 3 + 1] = ds * inv_logit_scale;
+            det_rows[(size_t)r * 3 + 2] = 0.f;
+        } else {
+            unsafeAtomicAdd(loss_sum, (lse - row[label]) * loss_scale);
+            unsafeAtomicAdd(dscale_sum, ds * inv_logit_scale);
+        }
     }
 }
 
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void siglip_rows_kernel(const float* __restric
                                                            int R, int N, int label_offset, int negative_only, float bias,
                                                            float loss_scale, float grad_scale, float inv_logit_scale,
                                                            float* __restrict__ loss_sum, float* __restrict__ dscale_sum,
-                                                           float* __restrict__ dbias_sum) {
+                                                           float* __restrict__ dbias_sum, float* __restrict__ det_rows) {
     __shared__ float red[8];
     const int r = blockIdx.x;
     const float* row = logits + (size_t)r * ld;
@@ -88,9 +94,15 @@ __global__ __launch_bounds__(256) void siglip_rows_kernel(const float* __restric
     ds = block_sum(ds, red);
     dbs = block_sum(dbs, red);
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(loss_sum, ls * loss_scale);
-        unsafeAtomicAdd(dscale_sum, ds * inv_logit_scale);
-        unsafeAtomicAdd(dbias_sum, dbs);
+        if (det_rows) {
+            det_rows[(size_t)r * 3] = ls * loss_scale;
+            det_rows[(size_t)r * 3 + 1] = ds * inv_logit_scale;
+            det_rows[(size_t)r * 3 + 2] = dbs;
+        } else {
+            unsafeAtomicAdd(loss_sum, ls * loss_scale);
+            unsafeAtomicAdd(dscale_sum, ds * inv_logit_scale);
+            unsafeAtomicAdd(dbias_sum, dbs);
+        }
     }
 }
 
@@ -161,23 +173,23 @@ extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ld
 
 extern "C" int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset,
                                    float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
-                                   float* dscale_sum, ocn_stream_t stream) {
+                                   float* dscale_sum, float* det_rows, ocn_stream_t stream) {
     OCN_CHECK_ARG(logits && G && loss_sum && dscale_sum, "ocn_softmax_ce_rows: null operand");
     OCN_CHECK_ARG(R > 0 && N > 0 && ld >= N && ldg >= N, "ocn_softmax_ce_rows: bad shape R=%d N=%d", R, N);
     OCN_CHECK_ARG(label_offset >= 0 && label_offset + R <= N, "ocn_softmax_ce_rows: labels [%d,%d) outside N=%d", label_offset, label_offset + R, N);
     hipLaunchKernelGGL(softmax_ce_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, (bf16*)G, ldg, R, N,
-                       label_offset, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum);
+                       label_offset, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, det_rows);
     OCN_CHECK_LAUNCH("ocn_softmax_ce_rows");
     return OCN_OK;
 }
 
 extern "C" int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,
                                float bias, float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
-                               float* dscale_sum, float* dbias_sum, ocn_stream_t stream) {
+                               float* dscale_sum, float* dbias_sum, float* det_rows, ocn_stream_t stream) {
     OCN_CHECK_ARG(logits && G && loss_sum && dscale_sum && dbias_sum, "ocn_siglip_rows: null operand");
     OCN_CHECK_ARG(R > 0 && N > 0 && ld >= N && ldg >= N, "ocn_siglip_rows: bad shape R=%d N=%d", R, N);
     hipLaunchKernelGGL(siglip_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, (bf16*)G, ldg, R, N,
-                       label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum);
+                       label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum, det_rows);
     OCN_CHECK_LAUNCH("ocn_siglip_rows");
     return OCN_OK;
 }

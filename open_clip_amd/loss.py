@@ -79,6 +79,7 @@ class _PairTerm:
         self.logits = None
         self._bias = None
         self._onehot = None  # (label_offset, grad_scale) once softmax_ce has filled G
+        self.deterministic = False  # reproducible sums (set by the loss Function): the rows' loss / d-scale contributions are added in a fixed order
         self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
 
     def compute_logits(self, bias=None):
@@ -101,6 +102,15 @@ class _PairTerm:
         that is 256 MiB of G written instead of 512 MiB of fp32 logits written and read three times besides."""
         # both kernels leave G = softmax * grad_scale; the -onehot * grad_scale part of the logit gradient is applied in dX / dY below, exactly
         self._onehot = (int(label_offset), float(grad_scale))
+        if self.deterministic:
+            # reproducible form: materialised logits, every row's contributions written to their own slot and added up in a fixed order (the fused
+            # form's epilogues add per-wave partial sums atomically)
+            rows = torch.empty(self.R, 3, dtype=F32, device=self.X.device)
+            ops.softmax_ce_rows(self._materialise(), self.G, self.N, label_offset, loss_scale, grad_scale, 1.0, acc[0:1], acc[1:2], det_rows=rows)
+            tot = torch.zeros(3, dtype=F32, device=self.X.device)
+            ops.colsum_f32(rows, tot, deterministic=True)
+            acc[0:2].add_(tot[0:2])
+            return
         if self._bias is None and USE_FUSED_CE and ops.fused_logits_ce_supported(self.R, self.N, self.xs16.shape[1]):
             ops.fused_logits_ce(self.xs16, self.y16, self.G, self.N, label_offset, loss_scale, grad_scale, acc[0:1], acc[1:2])
             return
@@ -109,6 +119,14 @@ class _PairTerm:
     def siglip(self, label_offset, negative_only, loss_scale, grad_scale, acc):
         """acc[0] += loss, acc[1] += sum(G * logits) (bias included: the caller subtracts bias * acc[2]), acc[2] += sum(G)"""
         self._onehot = None if negative_only else (int(label_offset), float(grad_scale))  # G = sigmoid * grad_scale; the positives' -1 in dX / dY
+        if self.deterministic:
+            rows = torch.empty(self.R, 3, dtype=F32, device=self.X.device)
+            ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
+                            acc[0:1], acc[1:2], acc[2:3], det_rows=rows)
+            tot = torch.zeros(3, dtype=F32, device=self.X.device)
+            ops.colsum_f32(rows, tot, deterministic=True)
+            acc[0:3].add_(tot)
+            return
         ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
                         acc[0:1], acc[1:2], acc[2:3])
 
@@ -134,7 +152,7 @@ class _PairTerm:
         Np = _round_up(self.N, 8)
         Ep = self.xs16.shape[1]
         out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
-        ops.gemm_tn_accum(self.G[:, :Np], self.xs16, out)
+        ops.gemm_tn_accum(self.G[:, :Np], self.xs16, out, None, 1.0, self.deterministic)
         if self._onehot is not None:
             off, gs = self._onehot
             out[off:off + self.R].sub_(self.xs16.float(), alpha=gs)  # xs16 = bf16(s X): the rows the G^T (s X) product multiplied
@@ -160,10 +178,16 @@ def _device_scalar(t, dev):
     return t.detach().to(device=dev, dtype=F32).reshape(1)
 
 
+def _term(X, Y, s, deterministic):
+    t = PairTerm(X, Y, s)
+    t.deterministic = bool(deterministic)
+    return t
+
+
 class _ClipLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image_features, text_features, logit_scale, local_loss, gather_with_grad, rank, world_size, row_sharded=False, comm=None,
-                logit_bias=None):
+                logit_bias=None, deterministic=False):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         dev = I.device
         s = _device_scalar(logit_scale, dev)  # stays on the device: no host synchronisation inside the step
@@ -176,8 +200,8 @@ class _ClipLossFn(torch.autograd.Function):
             I_all, T_all = allp[:, :E].contiguous(), allp[:, E:].contiguous()
         if world_size == 1:
             # loss.py:109-110: li = s I T^T, lt = s T I^T ; labels arange(B)
-            ti = PairTerm(I, T, s).compute_logits()
-            tt = PairTerm(T, I, s).compute_logits()
+            ti = _term(I, T, s, deterministic).compute_logits()
+            tt = _term(T, I, s, deterministic).compute_logits()
             for term in (ti, tt):
                 term.softmax_ce(0, 0.5 / B, 0.5 / B, acc)
             dI = ti.dX() + tt.dY()
@@ -185,8 +209,8 @@ class _ClipLossFn(torch.autograd.Function):
             d_all = None
         elif local_loss:
             # loss.py:103-104 + :82-83: li = s I_loc T_all^T, lt = s T_loc I_all^T, labels arange(B) + B*rank
-            ti = PairTerm(I, T_all, s).compute_logits()
-            tt = PairTerm(T, I_all, s).compute_logits()
+            ti = _term(I, T_all, s, deterministic).compute_logits()
+            tt = _term(T, I_all, s, deterministic).compute_logits()
             for term in (ti, tt):
                 term.softmax_ce(B * rank, 0.5 / B, 0.5 / B, acc)
             dI, dT = ti.dX(), tt.dX()            # through the local operands
@@ -201,8 +225,8 @@ class _ClipLossFn(torch.autograd.Function):
             # other ranks' rows arrives by one reduce-scatter of [N, 2E] -- done here, since the loss computes its gradients
             # in the forward.  6 GEMMs of 2*B*N*E flops instead of 6 of 2*N*N*E.
             N = world_size * B
-            ti = PairTerm(I, T_all, s).compute_logits()
-            tt = PairTerm(T, I_all, s).compute_logits()
+            ti = _term(I, T_all, s, deterministic).compute_logits()
+            tt = _term(T, I_all, s, deterministic).compute_logits()
             for term in (ti, tt):
                 term.softmax_ce(B * rank, 0.5 / N, 0.5 / N, acc)
             dI, dT = ti.dX(), tt.dX()
@@ -216,8 +240,8 @@ class _ClipLossFn(torch.autograd.Function):
         else:
             # loss.py:106-107: li = s I_all T_all^T, lt = li^T ; labels arange(N)
             N = world_size * B
-            ti = PairTerm(I_all, T_all, s).compute_logits()
-            tt = PairTerm(T_all, I_all, s).compute_logits()
+            ti = _term(I_all, T_all, s, deterministic).compute_logits()
+            tt = _term(T_all, I_all, s, deterministic).compute_logits()
             for term in (ti, tt):
                 term.softmax_ce(0, 0.5 / N, 0.5 / N, acc)
             dI_all = ti.dX() + tt.dY()
@@ -247,7 +271,7 @@ class _ClipLossFn(torch.autograd.Function):
         # logit_bias shifts every logit of a row alike: its gradient is exactly zero (the softmax gradient of a row sums to 0), but it is
         # a real gradient, as in the reference (loss.py:111-113) -- DDP then sees the parameter reduced like every other one
         dbias = (gout * 0.0).reshape(()) if has_bias else None
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None, None, dbias
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, None, None, None, None, None, None, dbias, None
 
 
 PairTerm = _PairTerm  # the one seam tests replace to exercise the collective plumbing on CPU/gloo
@@ -257,8 +281,12 @@ class NativeClipLoss(nn.Module):
     """``open_clip.loss.ClipLoss`` (loss.py:57-141) on the HIP path.  ``cache_labels`` is accepted for
     signature parity; labels are an arange predicate inside the kernel (nothing to cache)."""
 
-    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, row_sharded=False, comm=None):
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, row_sharded=False, comm=None,
+                 deterministic=False):
         super().__init__()
+        # native extension: loss and d/d logit_scale summed in a fixed order (materialised logits, one slot per row) instead of fp32 atomics --
+        # the loss's share of torch.use_deterministic_algorithms; NativeCLIP(deterministic=True) is the towers'
+        self.deterministic = bool(deterministic)
         self.comm = comm  # optional open_clip_amd.comm.NativeComm: the collectives through the C ABI instead of torch.distributed
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size = rank, world_size
@@ -270,13 +298,13 @@ class NativeClipLoss(nn.Module):
         # loss.py:111-113 adds logit_bias to both logit matrices; a constant added to every logit of a row changes neither the
         # softmax nor the cross-entropy: the loss ignores its value and hands back the exact (zero) gradient
         loss = _ClipLossFn.apply(image_features, text_features, logit_scale, self.local_loss, self.gather_with_grad,
-                                 self.rank, self.world_size, self.row_sharded, self.comm, logit_bias)
+                                 self.rank, self.world_size, self.row_sharded, self.comm, logit_bias, self.deterministic)
         return {"contrastive_loss": loss} if output_dict else loss
 
 
 class _SigLipLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size, comm=None, chunk_size=0):
+    def forward(ctx, image_features, text_features, logit_scale, logit_bias, rank, world_size, comm=None, chunk_size=0, deterministic=False):
         I, T = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         dev = I.device
         s, b = _device_scalar(logit_scale, dev), _device_scalar(logit_bias, dev)
@@ -296,13 +324,13 @@ class _SigLipLossFn(torch.autograd.Function):
             dI = torch.empty(B, E, dtype=F32, device=dev)
             dT_all = torch.zeros(T_all.shape[0], E, dtype=F32, device=dev)
             for i in range(0, B, chunk_size):
-                term = PairTerm(I[i:i + chunk_size], T_all, s).compute_logits(bias=b)
+                term = _term(I[i:i + chunk_size], T_all, s, deterministic).compute_logits(bias=b)
                 term.siglip(B * rank + i, 0, 1.0 / B, 1.0 / B, acc)
                 dI[i:i + chunk_size] = term.dX()
                 dT_all += term.dY()
                 del term
         else:
-            term = PairTerm(I, T_all, s).compute_logits(bias=b)
+            term = _term(I, T_all, s, deterministic).compute_logits(bias=b)
             term.siglip(B * rank, 0, 1.0 / B, 1.0 / B, acc)
             dI = term.dX()
             dT_all = term.dY().contiguous()
@@ -320,7 +348,7 @@ class _SigLipLossFn(torch.autograd.Function):
             _reduce_scatter_sum(dT, dT_all, comm)
         else:
             dT = dT_all
-        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None, None, None
+        return (dI * gout).to(idt), (dT * gout).to(tdt), acc[1] * gout, acc[2] * gout, None, None, None, None, None
 
 
 class NativeSigLipLoss(nn.Module):
@@ -329,13 +357,15 @@ class NativeSigLipLoss(nn.Module):
     and one reduce-scatter in the backward -- the loss value and every gradient are identical.  ``chunk_size`` > 0 evaluates the image
     rows in chunks of that many (loss.py:369-404: peak memory O(chunk_size * N) for the logits and their gradient)."""
 
-    def __init__(self, cache_labels=False, rank=0, world_size=1, dist_impl=None, chunk_size=0, comm=None):
+    def __init__(self, cache_labels=False, rank=0, world_size=1, dist_impl=None, chunk_size=0, comm=None, deterministic=False):
         super().__init__()
+        self.deterministic = bool(deterministic)  # as NativeClipLoss: the three sums in a fixed order instead of fp32 atomics
         self.comm = comm
         self.cache_labels, self.rank, self.world_size = cache_labels, rank, world_size
         self.dist_impl = dist_impl or "bidir"
         self.chunk_size = chunk_size
 
     def forward(self, image_features, text_features, logit_scale, logit_bias, output_dict=False):
-        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size, self.comm, self.chunk_size)
+        loss = _SigLipLossFn.apply(image_features, text_features, logit_scale, logit_bias, self.rank, self.world_size, self.comm, self.chunk_size,
+                                   self.deterministic)
         return {"contrastive_loss": loss} if output_dict else loss

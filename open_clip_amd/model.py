@@ -244,22 +244,16 @@ class _BlockFn(torch.autograd.Function):
         M, C = x.shape
         Fd = wfc.shape[0]
         dy16 = _take_twin(dy, cache)
-        dy_colsum = _take_colsum(dy)
+        dy_colsum = _take_colsum(dy)  # only the head publishes one (B rows: free): the LAST block's c_proj bias gradient as an fp32 column sum
         dy = dy.contiguous()
         # one zeroed fp32 arena for all of the block's parameter gradients (wgrad kernels accumulate atomically)
         grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
-        # Bias gradients of c_proj and out_proj = column sums of dy resp. dxmid.  Both come out of a LayerNorm backward in fp32, and that kernel
-        # sums them there (``dcol``) before the values are rounded to the bf16 operand of the weight-gradient GEMM.  c_proj's arrives with dy
-        # (published by the kernel that produced it), out_proj's is taken by this block's own LN2 backward.  (Measured at batch 4096 against the
-        # fp32 GPU reference: the bias gradients' error does NOT move -- 5.1e-2 either way on the last text block: it is upstream bf16 noise of the
-        # summands amplified by the cancellation of a contrastive batch, not the rounding of the sum's operands.  Kept because it is the exact sum
-        # and one bias MFMA less per block; profiles/r04_parity_report.txt.)
+        # (Round 4 tried ALL c_proj / out_proj bias gradients as fp32 column sums taken inside the LayerNorm backward that produces dy / dxmid
+        # (``dcol``): on all rows it costs that kernel 3-4 % (0.5 ms per step) and moves no digit of the parity report -- the bias gradients'
+        # error at batch 4096 was a same-sign error of the summands, loss.py -- so the blocks keep the weight-gradient GEMM's own bias row.)
         if dy_colsum is not None:
             dbproj.copy_(dy_colsum)
-        # scratch bias row of the paired wgrad launch (below): a local of this function, so that the caching allocator cannot hand its memory to
-        # another tensor while the launch on the SIDE stream is still adding into it (it dies after the streams have joined)
-        dbo_scratch = ops.empty((C,), F32, x)
 
         dev = x.device
         # a locked block (lock_image_tower / lock_text_tower with some groups left trainable above it) still has to pass the gradient
@@ -273,7 +267,7 @@ class _BlockFn(torch.autograd.Function):
         with _Paired(dev, cache, pair) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dy16, g, dwproj, None if dy_colsum is not None else dbproj, 1.0, det)
-            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True, dcol=dbo)
+            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev, cache, pair) as side:
@@ -283,14 +277,12 @@ class _BlockFn(torch.autograd.Function):
         dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev, cache, pair) as side:
             if need_w and det:
-                side(ops.gemm_tn_accum, dxmid16, a, dwo, None, 1.0, True)
+                side(ops.gemm_tn_accum, dxmid16, a, dwo, dbo, 1.0, True)
                 side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv, 1.0, True)
             elif need_w:  # out-proj and QKV wgrads share their rows and their K = C: one launch (36 tiles, 7 M-splits instead of 28 + 9)
-                # (the paired launch takes both bias rows or neither: out_proj's, which LN2's backward has already summed in fp32, goes to a scratch row)
-                side(ops.gemm_tn_accum2, dxmid16, a, dwo, dbo_scratch, dqkv, h1, dwqkv, dbqkv)
-            dx_colsum = torch.zeros((C,), dtype=F32, device=dev)  # -> the previous block's c_proj bias gradient
-            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True, dcol=dx_colsum)
-        _publish_twin(dx, dx16, dx_colsum)
+                side(ops.gemm_tn_accum2, dxmid16, a, dwo, dbo, dqkv, h1, dwqkv, dbqkv)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
+        _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None, None)
@@ -375,16 +367,17 @@ class _PooledBlockFn(torch.autograd.Function):
         if dy_colsum is not None:
             dbproj.copy_(dy_colsum)
         else:
-            ops.colsum_f32(dy_p, dbproj)
+            ops.colsum_f32(dy_p, dbproj, cache.deterministic)
         df_p = ops.gemm_nt(ops.EPI_DGELU, dy16, cache.get(wproj, "t"), ops.empty((B, Fd), BF16, x), aux=f_p)
         dh2_p = ops.gemm_nt(ops.EPI_BF16, df_p, cache.get(wfc, "t"), ops.empty((B, C), BF16, x))
-        dxmid_p, dxmid16_p = ops.layernorm_bwd(dh2_p, xmid_p, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy_p, want_f32=True, want_bf16=True, dcol=dbo)
+        dxmid_p, dxmid16_p = ops.layernorm_bwd(dh2_p, xmid_p, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy_p, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
         det = cache.deterministic
         if need_w:
             ops.gemm_tn_accum(dy16, g_p, dwproj, None, 1.0, det)
             ops.gemm_tn_accum(df_p, h2_p, dwfc, dbfc, 1.0, det)
-            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, None, 1.0, det)
-        dres = torch.zeros((M, C), dtype=F32, device=x.device)  # what reaches x besides LayerNorm-1's all-row backward: nonzero on the pooled rows only
+            ops.gemm_tn_accum(dxmid16_p, a_p, dwo, dbo, 1.0, det)
+        # what reaches x besides LayerNorm-1's all-row backward lives on the B pooled rows only: it is ADDED into those rows of dx behind that kernel
+        # (ocn_scatter_add_rows) instead of travelling through a zero [M, C] fp32 residual-gradient matrix (1 GB of fills and reads per step)
         if single:
             kv, q_p, h1_p, mean1_p, rstd1_p = att
             w_t = cache.get(wqkv, "t")  # [C, 3C] bf16: columns [Wq^T | Wk^T | Wv^T]
@@ -395,9 +388,8 @@ class _PooledBlockFn(torch.autograd.Function):
             if need_w:
                 ops.gemm_tn_accum(dkv, h1, dwqkv[C:], dbqkv[C:], 1.0, det)
                 ops.gemm_tn_accum(dq_p, h1_p, dwqkv[:C], dbqkv[:C], 1.0, det)
-            # pooled rows: LayerNorm-1 backward of the query path + the residual x -> xmid, then scattered into the all-row residual input
-            dxp, _ = ops.layernorm_bwd(dh1q_p, x_p, ln1w, mean1_p, rstd1_p, dln1w, dln1b, dres=dxmid_p, want_f32=True, want_bf16=False)
-            ops.scatter_rows(dxp, rows, dres, B, 0, None)
+            # pooled rows: LayerNorm-1 backward of the query path + the residual x -> xmid
+            dxp, _ = ops.layernorm_bwd(dh1q_p, x_p, ln1w, mean1_p, rstd1_p, dln1w, dln1b, dres=dxmid_p, want_f32=True, want_bf16=False, deterministic=cache.deterministic)
         else:
             qkv, a = att
             # ---- attention and everything below it: every row (the pooled rows' queries read all keys / values) ----
@@ -408,10 +400,17 @@ class _PooledBlockFn(torch.autograd.Function):
             dh1 = ops.gemm_nt(ops.EPI_BF16, dqkv, cache.get(wqkv, "t"), ops.empty((M, C), BF16, x))
             if need_w:
                 ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv, 1.0, det)
+            dxp = None
+        if dxp is not None:
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
+            ops.scatter_add_rows(dxp, rows, dx, B, 0, dx16)
+        else:
+            # the all-query form keeps the full block's arithmetic to the bit (the residual gradient enters INSIDE the LayerNorm backward, where the
+            # compiler contracts it into an FMA): it is the form tests/test_model_gpu.py::test_pooled_last_block_equals_full_block proves exact
+            dres = torch.zeros((M, C), dtype=F32, device=x.device)
             ops.scatter_rows(dxmid_p, rows, dres, B, 0, None)  # the residual path x -> xmid carries gradient on the pooled rows only
-        dx_colsum = torch.zeros((C,), dtype=F32, device=x.device)  # -> the previous block's c_proj bias gradient
-        dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True, dcol=dx_colsum)
-        _publish_twin(dx, dx16, dx_colsum)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
+        _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None, None, None)
@@ -455,9 +454,9 @@ class _VisionEmbedFn(torch.autograd.Function):
         dev = emb.device
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
         dy0 = dx0.contiguous()
-        demb, _ = ops.layernorm_bwd(dy0, emb, lnw, mean, rstd, dlnw, dlnb, want_f32=True)
+        demb, _ = ops.layernorm_bwd(dy0, emb, lnw, mean, rstd, dlnw, dlnb, want_f32=True, deterministic=ctx.cache.deterministic)
         dpos, dcls = torch.zeros_like(pos), torch.zeros_like(cls)
-        dpatch = ops.embed_assemble_bwd(demb, dpos, dcls, B, G, width)
+        dpatch = ops.embed_assemble_bwd(demb, dpos, dcls, B, G, width, ctx.cache.deterministic)
         dw = torch.zeros(width, Kpad, dtype=F32, device=dev)
         ops.gemm_tn_accum(dpatch, patches, dw, None, 1.0, ctx.cache.deterministic)
         dconv = (dw if Kpad == KP else dw[:, :KP].contiguous()).view(conv_w.shape)
@@ -469,12 +468,13 @@ class _VisionEmbedFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 class _TextEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, text, table, pos, pack=None):
+    def forward(ctx, text, table, pos, pack=None, deterministic=False):
         if pack is None:
             x = ops.token_embed_fwd(text.contiguous(), table, pos)
         else:
             x = ops.token_embed_fwd_rows(pack.tokens, pack.posidx, table, pos)
         ctx.pack = pack
+        ctx.det = bool(deterministic)
         ctx.save_for_backward(text, table, pos)
         return x
 
@@ -484,11 +484,11 @@ class _TextEmbedFn(torch.autograd.Function):
         dtable, dpos = torch.zeros_like(table), torch.zeros_like(pos)
         dxv = dx.contiguous()
         if ctx.pack is None:
-            ops.token_embed_bwd_sorted(text.contiguous(), dxv, dtable, dpos)
+            ops.token_embed_bwd_sorted(text.contiguous(), dxv, dtable, dpos, ctx.det)
         else:
             B, L = text.shape
-            ops.token_embed_bwd_sorted_varlen(ctx.pack.tokens, ctx.pack.seq_off, B, L, dxv, dtable, dpos)
-        return None, dtable, dpos, None
+            ops.token_embed_bwd_sorted_varlen(ctx.pack.tokens, ctx.pack.seq_off, B, L, dxv, dtable, dpos, ctx.det)
+        return None, dtable, dpos, None, None
 
 
 class _TextPack:
@@ -573,7 +573,7 @@ class _HeadFn(torch.autograd.Function):
         ops.gemm_tn_accum(p16, dfeat16, dproj, None, 1.0, cache.deterministic)
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
         dcol = torch.zeros_like(lnw)  # column sums of dpooled = of dx (zero elsewhere): the last block's c_proj bias gradient, in fp32
-        dpooled, _ = ops.layernorm_bwd(dp32, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True, dcol=dcol)
+        dpooled, _ = ops.layernorm_bwd(dp32, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True, dcol=dcol, deterministic=cache.deterministic)
         dx = torch.zeros(xshape, dtype=F32, device=dy.device)
         dx16 = torch.zeros(xshape, dtype=BF16, device=dy.device)  # bf16 twin for the last block's dgrad / wgrad GEMMs
         ops.scatter_rows(dpooled, idx, dx, B, L, dx16)
@@ -988,7 +988,7 @@ class NativeCLIP(nn.Module):
         self._cache.single_query = bool(self.pooled_single_query)
         if self.pack_text:
             pack = (_pack if _pack is not None else _TextPack(text, self.vocab_size, self.attn_buckets)).finish()
-            x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack)
+            x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, pack, self.deterministic)
             if _pooled_last_block_ok(self):
                 x = self.transformer(x, self._cache, B, L, True, pack.layout, pack.last_row)  # [B, C]: the EOT rows
                 rows = torch.arange(B, device=x.device, dtype=torch.int32)
@@ -999,7 +999,7 @@ class NativeCLIP(nn.Module):
         # ids outside the vocabulary raise like nn.Embedding (model.py:399); the packed path gets the count with its plan's read-back
         if int(ops.token_range_check(text.contiguous(), self.vocab_size)) != 0:
             raise IndexError(f"index out of range in self: token id(s) outside [0, {self.vocab_size}) (token_embedding has {self.vocab_size} rows)")
-        x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
+        x = _TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, None, self.deterministic)
         idx = ops.argmax_rows(text.contiguous())
         if _pooled_last_block_ok(self):
             rows = torch.arange(B, device=x.device, dtype=torch.int32)

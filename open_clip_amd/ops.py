@@ -149,23 +149,25 @@ def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dcol=None):
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dcol=None, deterministic=False):
     """(dx fp32 | None, dx bf16 | None); ``dres`` = the residual branch's fp32 gradient, added in; dw / db are accumulated into;
-    ``dcol`` (fp32 [C], accumulated into): column sums of dx in fp32 = the bias gradient of the linear in front of this LayerNorm's input"""
+    ``dcol`` (fp32 [C], accumulated into): column sums of dx in fp32 = the bias gradient of the linear in front of this LayerNorm's input;
+    ``deterministic``: dw / db / dcol through per-workgroup slabs added in a fixed order instead of fp32 atomics"""
     M, C = x.shape
     is32 = dy.dtype == F32
     dx32 = empty((M, C), F32, x) if want_f32 else None
     dx16 = empty((M, C), BF16, x) if want_bf16 else None
+    ws = empty((_lib.load().ocn_layernorm_bwd_det_workspace_floats(M, C),), F32, x) if deterministic else None
     _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
               _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"),
-              _chk(dw, F32, "dw"), _chk(db, F32, "db"), _chk(dcol, F32, "dcol"), M, C, _stream())
+              _chk(dw, F32, "dw"), _chk(db, F32, "db"), _chk(dcol, F32, "dcol"), _chk(ws, F32, "det_workspace"), M, C, _stream())
     return dx32, dx16
 
 
-def colsum_f32(x, out):
-    """out[C] += column sums of x [R, C] (fp32)"""
+def colsum_f32(x, out, deterministic=False):
+    """out[C] += column sums of x [R, C] (fp32); ``deterministic``: a single, fixed order of additions"""
     R, C = x.shape
-    _lib.call("ocn_colsum_f32", _chk(x, F32, "x"), _chk(out, F32, "out"), R, C, _stream())
+    _lib.call("ocn_colsum_f32", _chk(x, F32, "x"), _chk(out, F32, "out"), R, C, int(deterministic), _stream())
     return out
 
 
@@ -285,10 +287,10 @@ def embed_assemble_fwd(patch_out, cls, pos, B, G, C):
     return emb
 
 
-def embed_assemble_bwd(demb, dpos, dcls, B, G, C):
+def embed_assemble_bwd(demb, dpos, dcls, B, G, C, deterministic=False):
     dpatch = empty((B * G, C), BF16, demb)
     _lib.call("ocn_embed_assemble_bwd", _chk(demb, F32, "demb"), _chk(dpatch, BF16, "dpatch"), _chk(dpos, F32, "dpos"),
-              _chk(dcls, F32, "dcls"), B, G, C, _stream())
+              _chk(dcls, F32, "dcls"), B, G, C, int(deterministic), _stream())
     return dpatch
 
 
@@ -308,15 +310,16 @@ def token_embed_bwd(text, dx, dtable, dpos):
               _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
 
 
-def token_embed_bwd_sorted(text, dx, dtable, dpos):
+def token_embed_bwd_sorted(text, dx, dtable, dpos, deterministic=False):
     """segment-reduce form of token_embed_bwd: ``dtable`` must be zero on entry.  The device sort of the B*L ids is index plumbing
     (torch.sort); all arithmetic is in ocn_token_embed_bwd_sorted."""
     B, L = text.shape
     vocab, C = dtable.shape
-    keys, order = torch.sort(text.reshape(-1))
+    keys, order = torch.sort(text.reshape(-1), stable=bool(deterministic))  # the reproducible form sums a run in sorted order: equal ids must keep their order
     is16 = dx.dtype == BF16
     _lib.call("ocn_token_embed_bwd_sorted", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"),
-              _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab, _stream())
+              _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"), B, L, C, vocab,
+              int(deterministic), _stream())
 
 
 def seq_pack_plan(text, vocab=None, buckets=False):
@@ -364,15 +367,15 @@ def token_embed_fwd_rows(tokens, posidx, table, pos):
     return x
 
 
-def token_embed_bwd_sorted_varlen(tokens, seq_off, B, L, dx, dtable, dpos):
+def token_embed_bwd_sorted_varlen(tokens, seq_off, B, L, dx, dtable, dpos, deterministic=False):
     """packed-row form of token_embed_bwd_sorted (``tokens`` = the M packed ids; ``dtable`` zero on entry)"""
     vocab, C = dtable.shape
     M = tokens.numel()
-    keys, order = torch.sort(tokens)
+    keys, order = torch.sort(tokens, stable=bool(deterministic))
     is16 = dx.dtype == BF16
     _lib.call("ocn_token_embed_bwd_sorted_varlen", _chk(keys, torch.int64, "sorted_tokens"), _chk(order, torch.int64, "order"),
               _chk(dx, BF16 if is16 else F32, "dx"), int(is16), _chk(dtable, F32, "dtable"), _chk(dpos, F32, "dpos"),
-              _chk(seq_off, torch.int32, "seq_off"), B, L, M, C, vocab, _stream())
+              _chk(seq_off, torch.int32, "seq_off"), B, L, M, C, vocab, int(deterministic), _stream())
 
 
 def argmax_rows(text):
@@ -402,6 +405,13 @@ def scatter_rows(d, idx, dx, B, L, dx16=None):
     return dx
 
 
+def scatter_add_rows(d, idx, dx, B, L, dx16=None):
+    """dx[row_b] += d[b]; dx16[row_b] = bf16(dx[row_b])"""
+    C = d.shape[1]
+    _lib.call("ocn_scatter_add_rows", _chk(d, F32, "d"), _chk(idx, torch.int32, "idx"), _chk(dx, F32, "dx"), _chk(dx16, BF16, "dx16"), B, L, C, _stream())
+    return dx
+
+
 def l2norm_fwd(x, eps=1e-12):
     B, E = x.shape
     y, y16, inv = empty((B, E), F32, x), empty((B, E), BF16, x), empty((B,), F32, x)
@@ -417,11 +427,12 @@ def l2norm_bwd(dy, y, inv):
 
 
 # ---- losses ---------------------------------------------------------------------------------------------------
-def softmax_ce_rows(logits, G, N, label_offset, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum):
+def softmax_ce_rows(logits, G, N, label_offset, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, det_rows=None):
+    """``det_rows`` (fp32 [R, 3]): the rows' contributions are written there instead of being added atomically (reproducible form)"""
     pl, ld = _chk2d(logits, F32, "logits")
     pg, ldg = _chk2d(G, BF16, "G")
     _lib.call("ocn_softmax_ce_rows", pl, ld, pg, ldg, logits.shape[0], N, int(label_offset), float(loss_scale), float(grad_scale),
-              float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _stream())
+              float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _chk(det_rows, F32, "det_rows"), _stream())
 
 
 def fused_logits_ce(xs16, y16, G, N, label_offset, loss_scale, grad_scale, loss_sum, dscale_sum):
@@ -440,12 +451,12 @@ def fused_logits_ce_supported(R, N, E):
     return E % 128 == 0 and N % 8 == 0 and R >= 256
 
 
-def siglip_rows(logits, G, N, label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum):
+def siglip_rows(logits, G, N, label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum, det_rows=None):
     pl, ld = _chk2d(logits, F32, "logits")
     pg, ldg = _chk2d(G, BF16, "G")
     _lib.call("ocn_siglip_rows", pl, ld, pg, ldg, logits.shape[0], N, int(label_offset), int(negative_only), float(bias),
               float(loss_scale), float(grad_scale), float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"),
-              _chk(dscale_sum, F32, "dscale_sum"), _chk(dbias_sum, F32, "dbias_sum"), _stream())
+              _chk(dscale_sum, F32, "dscale_sum"), _chk(dbias_sum, F32, "dbias_sum"), _chk(det_rows, F32, "det_rows"), _stream())
 
 
 # ---- optimizer ----------------------------------------------------------------------------------------------------

@@ -212,13 +212,18 @@ def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference():
     logits + cross-entropy) against the chunked fp32 GPU reference, which the previous test pins to the CPU oracle at batch 512: features, loss
     and ALL 302 gradients.
 
-    Tolerances are the ones every other end-to-end test uses (tests/test_model_gpu.py) with ONE documented exception.  Bias and LayerNorm-bias
-    gradients are column sums over thousands of rows whose terms cancel (a contrastive batch at initialisation: the row gradients nearly sum to
-    zero), so the bf16 noise of the summands -- not of the summation: taking the sums from fp32 values changes nothing, profiles/r04_parity_report.txt
-    -- is amplified by |sum of |terms|| / |sum|, which grows with the batch: 3.9e-2 at batch 8, 4.3e-2 at 512, 5.2e-2 at 4096 on the last text
-    block.  That is a property of the amp_bf16 POLICY, and it is measured here: the same step as plain PyTorch eager operators under
-    torch.amp.autocast(bf16) (the reference's own --precision amp_bf16 on this GPU, oracle/torch_eager.py) against the same fp32 reference.  A 1-D
-    gradient may exceed its 5e-2 bound only as far as 1.25 x what that policy costs the same tensor in eager PyTorch."""
+    Bound at this batch: EVERY gradient within 2e-2 rel-L2 (measured: worst 1.3e-2, 1-D worst 1.2e-2) -- tighter than the tolerance classes of
+    the small-batch tests (3.5e-2 matrices / 5e-2 1-D, tests/test_model_gpu.py), which stay as they are because batches of 8-24 are noisier.
+    The same step as plain PyTorch eager operators under torch.amp.autocast(bf16) (the reference's own --precision amp_bf16 on this GPU,
+    oracle/torch_eager.py) is measured against the same fp32 reference as a yardstick of what the POLICY costs: the native path must not be
+    less accurate than it (medians of the 1-D and of the matrix gradients).
+
+    History (profiles/r04_parity_report.txt): this test is what found the loss kernel's common-mode bias.  Bias / LayerNorm-bias gradients are
+    column sums over thousands of rows that nearly cancel (a contrastive batch at initialisation), which amplifies any error that has the SAME
+    sign in every row: the label entry (p - 1) * grad_scale of the logit gradient, rounded to bf16, lost its p in every row -- the 1-D gradients of
+    the last text block stood at 5.2e-2 (1.04 of their bound; eager amp_bf16: 1.8e-2) and every other gradient at twice eager's error.  With the
+    one-hot part applied exactly (loss.py::_PairTerm.dX / dY) they are at 1.1e-2, below eager's.  Taking the column sums from fp32 values
+    (LayerNorm backward's dcol) had changed nothing: the error was in the summands, not in the summation."""
     from oracle import gpu_fp32, torch_eager
     from tests.test_model_gpu import FEAT_TOL, LOSS_TOL, _build, _grad_tol, _step
     cfg = get_model_config("ViT-B-32")
@@ -246,23 +251,18 @@ def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference():
     for k, p in model.named_parameters():
         ref = grads[k]
         rel = float((p.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
-        tol = _grad_tol(float(ref.norm()), gmax, ref.ndim)
-        if ref.ndim <= 1:
-            tol = max(tol, 1.25 * amp_rel[k])
+        tol = min(_grad_tol(float(ref.norm()), gmax, ref.ndim), 2e-2)
         worst.append((rel / tol, rel, k))
     worst.sort(reverse=True)
     for frac, rel, k in worst[:12]:
-        _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   grad rel_l2={rel:.3e} ({frac:.2f} of its tolerance; eager amp_bf16 {amp_rel[k]:.3e}) {k}")
-    one_d = sorted((rel, k) for _, rel, k in worst if grads[k].ndim <= 1)
-    amp_1d = sorted(amp_rel[k] for k in grads if grads[k].ndim <= 1)
-    amp_2d = max(amp_rel[k] for k in grads if grads[k].ndim >= 2)
-    over = [(rel, k) for _, rel, k in worst if grads[k].ndim <= 1 and rel > 5e-2]
-    _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   1-D gradients: native median rel_l2 {one_d[len(one_d) // 2][0]:.3e}, worst {one_d[-1][0]:.3e} ({one_d[-1][1]}); "
-            f"eager amp_bf16 median {amp_1d[len(amp_1d) // 2]:.3e}, worst {amp_1d[-1]:.3e}; matrices: native worst "
-            f"{max(rel for _, rel, k in worst if grads[k].ndim >= 2):.3e}, eager amp_bf16 worst {amp_2d:.3e}; {len(over)} 1-D tensors above 5e-2: "
-            + ", ".join(f"{k} {rel:.3e}" for rel, k in over))
+        _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   grad rel_l2={rel:.3e} ({frac:.2f} of its bound; eager amp_bf16 {amp_rel[k]:.3e}) {k}")
+    med = lambda v: sorted(v)[len(v) // 2]
+    nat_1d, nat_2d = [rel for _, rel, k in worst if grads[k].ndim <= 1], [rel for _, rel, k in worst if grads[k].ndim >= 2]
+    amp_1d, amp_2d = [amp_rel[k] for k in grads if grads[k].ndim <= 1], [amp_rel[k] for k in grads if grads[k].ndim >= 2]
+    _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   1-D gradients: native median rel_l2 {med(nat_1d):.3e} worst {max(nat_1d):.3e}; eager amp_bf16 median {med(amp_1d):.3e} "
+            f"worst {max(amp_1d):.3e}; matrices: native median {med(nat_2d):.3e} worst {max(nat_2d):.3e}; eager amp_bf16 median {med(amp_2d):.3e} worst {max(amp_2d):.3e}")
     assert len(worst) == 302 and worst[0][0] <= 1.0, worst[0]
-    assert len(over) <= 8, over  # the exception stays an exception
+    assert med(nat_1d) <= 1.1 * med(amp_1d) and med(nat_2d) <= 1.1 * med(amp_2d), "the native step is less accurate than eager PyTorch under the same amp_bf16 policy"
 
 
 def test_eval_and_inference_mode_calls(dev):

@@ -32,6 +32,13 @@ if has abnt_knobs; then  # cache-policy flips of the epilogues (developer build)
   for k in 0 2 8; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $k --only res --json $O/${TAG}_abnt.jsonl >> $O/${TAG}_abnt_knobs.txt 2>&1; done
   stamp abnt_knobs
 fi
+if has abtail; then  # half-tile tail round of the persistent NT GEMM on / off (developer build, knob 0x200000 = whole tail tiles), alternating
+  for i in 1 2; do
+    OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob 0 --json $O/${TAG}_abtail.jsonl >> $O/${TAG}_abtail_on.txt 2>&1
+    OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob 2097152 --json $O/${TAG}_abtail.jsonl >> $O/${TAG}_abtail_off.txt 2>&1
+  done; stamp abtail
+fi
+if has yard; then timeout 400 python tools/gemm_vendor_yardstick.py > $O/${TAG}_gemm_vs_vendor.txt 2>&1; stamp yard; fi
 if has abstep; then  # whole step: this tree against the round-3 library on the same box, alternating
   for i in 1 2; do
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_abstep_new.json
@@ -39,6 +46,11 @@ if has abstep; then  # whole step: this tree against the round-3 library on the 
   done; stamp abstep
 fi
 if has bench; then timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
+if has models; then  # BASELINE configs 4 / 5 through the same bench on one GPU (sanity lines, 3 steps)
+  Q2="--no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-roofline --no-extra-lines"
+  timeout 300 python bench.py --model ViT-H-14 --siglip --local-batch 1024 --grad-checkpointing --steps 3 --warmup 1 $Q2 2>&1 | grep '^{' > $O/${TAG}_h14_bench.json
+  timeout 300 python bench.py --model ViT-L-14 --local-batch 2048 --grad-checkpointing --steps 3 --warmup 1 $Q2 2>&1 | grep '^{' > $O/${TAG}_l14_bench.json; stamp models
+fi
 if has lines; then
   timeout 300 python bench.py --steps 8 --warmup 2 --h2d $QUIET > $O/${TAG}_bench_h2d.log 2>&1
   timeout 300 python bench.py --steps 8 --warmup 2 --deterministic $QUIET --no-roofline > $O/${TAG}_bench_det.log 2>&1; stamp lines
