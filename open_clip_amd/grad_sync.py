@@ -6,11 +6,12 @@ ONE GPU before any byte moves over xGMI).  The native backward already leaves th
 block writes its twelve parameter gradients into ONE zeroed fp32 arena (``model._grad_arena``), and autograd hands those views to
 ``.grad`` without copying.  ``NativeGradSync`` therefore reduces IN PLACE:
 
-  * a post-accumulate hook per parameter counts a group (one residual block; the embedding / head leftovers of a tower) down;
+  * a post-accumulate hook per parameter counts a group (one residual block; a tower's head; a tower's embeddings) down;
   * when a group is complete its ``.grad`` tensors are merged into flat address ranges (one per block when autograd kept the arena
     views; whatever they are otherwise -- correctness never depends on the aliasing) and each range is all-reduced (mean) on a
     communication stream that waits for the streams the backward runs on: the collectives of block *i* run under the backward of
-    blocks *i-1 ...*, in reverse layer order, as DDP's buckets do;
+    blocks *i-1 ...*, in reverse layer order, as DDP's buckets do; ranges below ``PACK_BELOW`` elements (LayerNorm vectors, the class /
+    positional embeddings outside an arena) are packed into one staging buffer per group and share ONE collective;
   * ``finish()`` (call before ``optimizer.step()``) reduces what is left (0-d parameters such as ``logit_scale``; groups that did not
     complete because a parameter got no gradient) and makes the current stream wait for the communication stream.
 
@@ -26,13 +27,19 @@ from contextlib import contextmanager
 import torch
 
 _BLOCK = re.compile(r"^(.*resblocks\.\d+)\.")
+_HEAD = re.compile(r"^(visual\.(ln_post|proj|attn_pool)|ln_final|text_projection)\b")
+PACK_BELOW = 1 << 16  # elements: flat ranges smaller than this share one staging buffer and one collective per group
 
 
 def _group_key(name: str) -> str:
+    """one group per residual block; per tower, the HEAD (final LayerNorm, projection: their gradients exist before the last block's backward
+    starts, so their collective runs under the whole tower's backward) and the EMBEDDINGS (patch / token / positional / class embedding,
+    ln_pre: complete only when the tower's backward ends)"""
     m = _BLOCK.match(name)
     if m:
         return m.group(1)
-    return "visual.*" if name.startswith("visual.") else "text.*"
+    tower = "visual" if name.startswith("visual.") else "text"
+    return f"{tower}.head" if _HEAD.match(name) else f"{tower}.embed"
 
 
 def flat_ranges(tensors):
@@ -151,18 +158,35 @@ class NativeGradSync:
         ranges = flat_ranges(grads)
         self.stats["ranges_per_group"] = (self.stats["ranges_per_group"] + [len(ranges)])[-64:]  # bounded: the last step's groups
         if cs is None:
-            for flat, _ in ranges:
-                self._allreduce_mean(flat)
+            self._reduce_ranges(ranges)
             return
         cs.wait_stream(torch.cuda.current_stream(dev))      # the stream the hook (and the producing backward) runs on
         side = getattr(self.model, "_tower_side", {}).get(dev)
         if side is not None:
             cs.wait_stream(side)                            # the image tower's backward, when the towers run on two streams
         with torch.cuda.stream(cs):
-            for flat, members in ranges:
-                self._allreduce_mean(flat)
+            self._reduce_ranges(ranges)
+            for _, members in ranges:
                 for m in members:
                     m.record_stream(cs)
+
+    def _reduce_ranges(self, ranges):
+        """large ranges in place, one collective each; the small ones of the group through ONE packed fp32 buffer (which ranges are small
+        depends on their sizes only, so every rank packs the same ones in the same order)"""
+        small = [flat for flat, _ in ranges if flat.numel() < PACK_BELOW and flat.dim() == 1]
+        if len(small) < 2:
+            small = []
+        packed_ids = {id(f) for f in small}
+        for flat, _ in ranges:
+            if id(flat) not in packed_ids:
+                self._allreduce_mean(flat)
+        if small:
+            packed = torch.cat([f.float() for f in small])
+            self._allreduce_mean(packed)
+            off = 0
+            for f in small:
+                f.copy_(packed[off:off + f.numel()])
+                off += f.numel()
 
     # ---- hooks -----------------------------------------------------------------------------------------------------------
     def _hook(self, p):

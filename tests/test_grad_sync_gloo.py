@@ -137,6 +137,8 @@ def test_native_grad_sync_equals_ddp_over_gloo(world, port):
                 assert np.allclose(g_native, g_ddp, rtol=1e-6, atol=1e-8), (rank, step, name)
         # the two arena-backed blocks went out as ONE flat range each, the module-autograd block as its two tensors
         assert sorted(stats["ranges_per_group"][:4]) == [1, 1, 1, 2], stats
+        # ... and those two (36 + 6 elements, below PACK_BELOW) shared one packed collective: no rank ever sent the 6-element bias on its own
+        assert 6 not in stats["order"] and 42 in stats["order"], stats["order"]
     # ranks agree with each other: gradients, and the order and sizes of the collectives they issued
     for r in range(1, world):
         for (n, _, a0), (_, _, a1) in zip(got[0][2], got[r][2]):
@@ -155,3 +157,17 @@ def test_flat_ranges_merges_only_adjacent_views_of_one_storage():
     flat = [f for f, m in r if f.numel() == 10][0]
     flat.mul_(2)  # in place through the flat view
     assert torch.equal(a.reshape(-1), torch.arange(6, dtype=torch.float32) * 2) and float(b[-1]) == 18.0 and float(arena[10]) == 10.0
+
+
+def test_group_keys_split_head_and_embeddings():
+    from open_clip_amd.grad_sync import _group_key
+    assert _group_key("visual.transformer.resblocks.3.mlp.c_fc.weight") == "visual.transformer.resblocks.3"
+    assert _group_key("transformer.resblocks.11.ln_1.bias") == "transformer.resblocks.11"
+    for n in ("visual.ln_post.weight", "visual.proj"):
+        assert _group_key(n) == "visual.head", n
+    for n in ("visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding", "visual.ln_pre.bias"):
+        assert _group_key(n) == "visual.embed", n
+    for n in ("ln_final.weight", "text_projection"):
+        assert _group_key(n) == "text.head", n
+    for n in ("token_embedding.weight", "positional_embedding"):
+        assert _group_key(n) == "text.embed", n
