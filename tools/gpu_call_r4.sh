@@ -45,14 +45,6 @@ if has abstep; then  # whole step: this tree against the round-3 library on the 
     (cd $GRAFT_REPO_ROOT/_ab/r03tree && timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline --no-cpu-baseline --no-eager-baseline --no-dense-text-line 2>&1 | grep '^{' >> $O/${TAG}_abstep_r03.json)
   done; stamp abstep
 fi
-if has abprio; then  # stream priorities of the two towers (image tower = side stream, text tower = the caller's stream), alternating
-  for i in 1 2; do
-    for v in "0 -" "-1 -" "0 -1"; do set -- $v
-      if [ "$2" = "-" ]; then unset OCN_MAIN_STREAM_PRIORITY; else export OCN_MAIN_STREAM_PRIORITY=$2; fi
-      OCN_TOWER_STREAM_PRIORITY=$1 timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' | python -c "import sys,json; [print('side', '$1', 'main', '$2', json.loads(l)['ms_per_step']) for l in sys.stdin]" >> $O/${TAG}_abprio.txt
-    done
-  done; unset OCN_MAIN_STREAM_PRIORITY; stamp abprio
-fi
 if has bench; then timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2>&1; stamp bench; fi
 if has models; then  # BASELINE configs 4 / 5 through the same bench on one GPU (sanity lines, 3 steps)
   Q2="--no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-roofline --no-extra-lines"
