@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--lr", type=float, default=5e-4)
     ap.add_argument("--lr-warmup-steps", type=int, default=10000, help="linear warm-up as the reference schedules it (params.py:288, scheduler.py:6-15)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-clock-sample", action="store_true", help="do not read the GPU's clock / power with rocm-smi during the timed steps")
     ap.add_argument("--grad-checkpointing", action="store_true")
     ap.add_argument("--keep-blocks", default="auto",
                     help="with --grad-checkpointing: blocks per tower whose activations are kept instead of recomputed -- 'auto' (as many as the "
@@ -250,6 +251,53 @@ def torch_eager_baseline(model_name, batch_size, dev):
             "what": "same step (ViT tower + text tower + ClipLoss + backward + torch.optim.AdamW + clamp) as plain PyTorch-ROCm eager ops under "
                     "torch.amp.autocast(bf16): F.linear / F.scaled_dot_product_attention / F.layer_norm / F.gelu / F.cross_entropy on this GPU "
                     "(oracle/torch_eager.py; the reference itself is not on the GPU box)"}
+
+
+class ClockSampler:
+    """shader clock and socket power of GPU 0 while the timed steps run, read with ``rocm-smi`` from a host thread (rank 0, one GPU only): the
+    2.5 PFLOP/s MFMA peak of the roofline is the 2.4 GHz figure, and this step runs the socket into its power limit (profiles/
+    r04_clock_power_under_load.txt).  Reported next to the roofline, never used to rescale ``peak`` or ``frac``.  Costs nothing on the GPU:
+    the thread sleeps between two ``rocm-smi`` child processes; any failure (tool missing, format changed) yields ``None``."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.rows, self._stop = period, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def read():
+        import re
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+        clk = re.search(r"sclk clock level:[^\n]*\((\d+)Mhz\)", out)
+        pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+        return (int(clk.group(1)) if clk else None, float(pw.group(1)) if pw else None)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.rows.append(self.read())
+            except Exception:
+                return
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=10)
+        clk = [c for c, _ in self.rows if c]
+        pw = [w for _, w in self.rows if w]
+        if not clk:
+            return None
+        mean = sum(clk) / len(clk)
+        return {"sclk_mhz_mean": round(mean), "sclk_mhz_min": min(clk), "sclk_mhz_max": max(clk),
+                "socket_power_w_mean": round(sum(pw) / len(pw)) if pw else None, "samples": len(clk),
+                "mfma_dense_bf16_tflops_at_this_clock": round(2500.0 * mean / 2400.0, 1),
+                "how": "rocm-smi --showclocks --showpower every 0.5 s from a host thread during the K timed steps; the roofline's peak stays the 2.4 GHz "
+                       "figure (2.5 PFLOP/s), this is what the power-limited clock of THIS run allows"}
 
 
 def main():
@@ -450,6 +498,7 @@ def main():
     # inside the timed region and counts in ``value``.
     EV = 10 if overlap_towers else 2
     timed_steps = 0
+    sampler = ClockSampler().start() if (rank == 0 and world == 1 and not args.no_clock_sample) else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         timer.on = (not args.no_roofline) and (i % EV == 0)
@@ -458,6 +507,7 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_under_load = sampler.stop() if sampler is not None else None
     timer.on = False
     model.tower_streams = overlap_towers
     if world > 1:
@@ -561,6 +611,8 @@ def main():
             ("step_model_tflops_per_gpu" if not model_ref.pack_text else "step_dense_equivalent_model_tflops_per_gpu"): round(value / world * flops_pair / 1e3, 1),
             "peak_hbm_gb_rank0": round(peak_bytes / 1e9, 1), "reserved_hbm_gb_rank0": round(torch.cuda.max_memory_reserved() / 1e9, 1),
         }
+        if clock_under_load is not None:
+            line["clock_under_load"] = clock_under_load
         if dense_text is not None:
             line["dense_text_tower"] = dense_text
         if reference_work is not None:
