@@ -298,7 +298,9 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         if (IS_DGELU) v = v * dgelu_unpack4(dq[hb][g]);  // gelu'(pre-activation), saved by the forward epilogue
                         if (IS_GELU) {
                             f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
-                            if (!ABL(a, 1)) {
+                            if (ABL(a, 0x400000) && EPI == OCN_EPI_BIAS_GELU) {  // developer knob: polynomial-CDF form (ocn_common.h)
+                                gelu_both_poly4(v, gv, dv);
+                            } else if (!ABL(a, 1)) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     float g1, d1;

@@ -99,6 +99,32 @@ OCN_DEV void gelu_both(float x, float& g, float& dg) {
     g = x * cdf;
     dg = fmaf(x * 0.39894228040143268f, e, cdf);
 }
+// Developer-build alternative of gelu_both for a register quad (selected by a developer knob of the NT GEMM; NOT in the product library until it has
+// been measured on the GPU): the normal CDF as an odd polynomial, Phi(x) - 1/2 = x Q(x^2) on |x| <= 4.25 with x clamped beyond (Phi(4.25) = 1 - 1.07e-5),
+// nine coefficients from tools/gelu_poly_fit.py (weighted minimax; |Phi error| <= 1.24e-5 in fp32, half of gelu_parts' 2.5e-5; tests/test_gelu_poly.py).
+// No v_rcp_f32, no copysign, and every plain operation is a <4 x float> one that gfx950 issues as two v_pk_*_f32: 12.5 VALU issue slots per element
+// (8 packed fma of the Horner chain = 4, clamp 1, v_exp_f32 = 4, seven more packed operations = 3.5) against 17.4 for gelu_both as compiled.
+OCN_DEV void gelu_both_poly4(f32x4 x, f32x4& g, f32x4& dg) {
+    f32x4 xc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xc[i] = __builtin_amdgcn_fmed3f(x[i], -4.25f, 4.25f);
+    const f32x4 u = xc * xc;
+    f32x4 q = u * 5.565356162e-11f + -5.328117947e-09f;
+    q = q * u + 2.255534781e-07f;
+    q = q * u + -5.626594884e-06f;
+    q = q * u + 9.342017438e-05f;
+    q = q * u + -1.108568278e-03f;
+    q = q * u + 9.815989994e-03f;
+    q = q * u + -6.634451449e-02f;
+    q = q * u + 3.989023566e-01f;
+    const f32x4 cdf = xc * q + 0.5f;
+    const f32x4 ku = (x * x) * -0.72134752044448170f;  // of the UNCLAMPED x: phi -> 0 beyond the clamp
+    f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(ku[i]);  // exp(-x^2/2)
+    g = x * cdf;
+    dg = (xc * 0.39894228040143268f) * e + cdf;
+}
 // The derivative saved for the backward (aux of OCN_EPI_BIAS_GELU / OCN_EPI_DGELU) is stored in 8 bits: gelu'(x) lies in
 // [-0.1290, 1.1290], q = round((gelu' + 0.13) * 200) in [0, 252], gelu' ~ q / 200 - 0.13 with |error| <= 0.0025 (uniform, unbiased;
 // rms 0.0014 -- what rounding a value in [0.5, 1) to bf16 costs).  Half the bytes of a bf16 copy in the forward epilogue's second
