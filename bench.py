@@ -1,7 +1,9 @@
 """bench.py -- image-text pairs/sec of the native CLIP training step (ViT-B-32, local batch 4096 per GPU).
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 launched under
-``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU, RCCL).  One "step" = zero_grad ->
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N>1 either a launcher started this file once per GPU
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or -- called
+as plain ``python bench.py --gpus N`` -- it starts the N ranks itself the same way (``launcher_command``) and hands their exit code on; a
+WORLD_SIZE that is not N, or fewer visible GPUs than N, is an error, never a silently smaller run.  One rank per GPU, RCCL.  One "step" = zero_grad ->
 forward (both towers) -> ClipLoss (packed feature all-gather + global logits when N>1) -> backward (DDP bucketed
 grad all-reduce overlapped) -> AdamW step -> logit_scale clamp, on synthetic inputs already resident in HBM.
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel (the NT MFMA GEMM) from HIP events recorded
@@ -300,14 +302,49 @@ class ClockSampler:
                        "figure (2.5 PFLOP/s), this is what the power-limited clock of THIS run allows"}
 
 
+def launcher_command(gpus, argv, port=None):
+    """the command ``python bench.py --gpus N ...`` turns into when no launcher started it: one rank per GPU under ``torch.distributed.run`` on
+    this node (the reference's launch contract, open_clip_train/distributed.py:80-166: torchrun's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), the
+    rendezvous on 127.0.0.1 and a free port"""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def check_launch(gpus, env):
+    """-> "spawn" (``--gpus N`` > 1 and no launcher: this process must start the N ranks itself), "rank" (started by a launcher whose
+    WORLD_SIZE is N) or "single" (N = 1, no launcher).  Anything else is an error: a line that claims N GPUs is never timed on fewer."""
+    launched = "RANK" in env or "LOCAL_RANK" in env
+    world = int(env.get("WORLD_SIZE", "1"))
+    if not launched:
+        if world != 1:
+            raise SystemExit(f"bench.py: WORLD_SIZE={world} without RANK / LOCAL_RANK in the environment: not a torchrun launch")
+        return "spawn" if gpus > 1 else "single"
+    if world != gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {gpus}: the line would not describe the run")
+    return "rank" if world > 1 else "single"
+
+
 def main():
     args = parse()
+    mode = check_launch(args.gpus, os.environ)
+    if mode == "spawn":
+        # `python bench.py --gpus N` as the driver calls it: start the N ranks here and hand their exit code on; rank 0 prints the one JSON line
+        import subprocess
+        raise SystemExit(subprocess.run(launcher_command(args.gpus, sys.argv[1:]), env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    if os.environ.get("OCN_BENCH_ONE_DEVICE") == "1":  # developer mode: every rank on GPU 0 (needs --dist-backend gloo)
+    one_device = os.environ.get("OCN_BENCH_ONE_DEVICE") == "1"  # developer mode: every rank on GPU 0 (needs --dist-backend gloo)
+    if one_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but this node shows {torch.cuda.device_count()} GPU(s): one rank per GPU is the contract "
+                         "(OCN_BENCH_ONE_DEVICE=1 with --dist-backend gloo is the developer mode that shares one)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world == 1 and args.force_ddp:
@@ -315,6 +352,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29777")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    rank_devices = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -322,6 +360,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.dist_backend)
+        assert dist.get_world_size() == args.gpus
+        # rank -> device map on the line: the line's n_gpus is what the process group itself reports
+        mine = {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
 
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.loss import NativeClipLoss
@@ -552,6 +596,7 @@ def main():
     extra_ok = (world == 1 and not args.no_extra_lines and not args.no_dense_text_line and args.model == "ViT-B-32" and not args.siglip and F_ACC == 1
                 and pipe is None and not args.grad_checkpointing and args.data_ranks == 1)
     if extra_ok and model.pack_text:
+        saved_flags = (model.pack_text, model.pooled_last_block, model.visual.pooled_last_block)
         try:
             model.pack_text = False
             model.pooled_last_block = model.visual.pooled_last_block = False
@@ -562,8 +607,7 @@ def main():
         except Exception as e:  # a sample must never take the bench line down with it
             reference_work = {"error": repr(e)[:300]}
         finally:
-            model.pack_text = True
-            model.pooled_last_block = model.visual.pooled_last_block = True
+            model.pack_text, model.pooled_last_block, model.visual.pooled_last_block = saved_flags
     if extra_ok and B == 4096:
         try:
             mb8 = micro + [synthetic_batch(cfg, B, seed=1234 + 1000 * j, rank=rank, device=dev) for j in range(1, 8)]
@@ -594,6 +638,9 @@ def main():
                                    + ("inputs from pinned host memory every step (uint8 pixels, async double-buffered H2D inside the timed region), " if args.h2d else "")
                                    + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
                                       if world > 1 else "world_size 1 (no all-gather)"),
+                       "dist_world_size": (torch.distributed.get_world_size() if world > 1 else 1),
+                       "dist_backend": ((("rccl (torch.distributed 'nccl')" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else "none")),
+                       "rank_devices": rank_devices, "one_device_developer_mode": one_device,
                        "model": args.model, "global_batch": B * F_ACC * world, "local_batch": B, "accum_freq": F_ACC, "parallelism": f"dp{world}",
                        "ddp": bool((world > 1 or args.force_ddp) and grad_sync is None), "bucket_cap_mb": args.bucket_cap_mb,
                        "gradient_allreduce": ("native per-block in-place all-reduce (open_clip_amd/grad_sync.py)" + (" over RCCL through the C ABI" if native_comm is not None else " over the process group")
