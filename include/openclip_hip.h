@@ -42,6 +42,14 @@ enum ocn_epilogue {
 };
 
 const char* ocn_last_error(void);
+/* ABI version of this header: ocn_version() of the library that is loaded must EQUAL it (open_clip_amd/_lib.py::load and
+ * __graft_entry__.build() check; a stale .so behind OCN_LIB_PATH would otherwise receive shifted arguments without any error).
+ *   102 (round 5)  ocn_sumsq_multi takes a per-chunk workspace (reproducible sum).  BREAKING since 101 and now carried by the number:
+ *                  ocn_layernorm_bwd / ocn_embed_assemble_bwd / ocn_token_embed_bwd_sorted[_varlen] / ocn_softmax_ce_rows / ocn_siglip_rows took
+ *                  extra arguments in round 4, and the logit-gradient matrix G written by ocn_softmax_ce_rows / ocn_fused_logits_ce /
+ *                  ocn_siglip_rows holds softmax (sigmoid) * grad_scale WITHOUT the -onehot term (the caller applies it as an exact rank-1
+ *                  update: open_clip_amd/loss.py::_PairTerm.dX / dY). */
+#define OCN_ABI_VERSION 102
 int ocn_version(void);
 
 /* ---- GEMMs (MFMA v_mfma_f32_32x32x16_bf16, fp32 accumulate) ------------------------------------
@@ -271,7 +279,9 @@ int ocn_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, i
  * the squared norm of every entry's gradient into out[0]. */
 int ocn_adamw_multi(const void* entries, const void* chunks, int n_chunks, float beta1, float beta2, float eps,
                     const float* gnorm_sq, float max_norm, ocn_stream_t stream);
-int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, ocn_stream_t stream);
+/* chunk_ws == NULL: every chunk adds its partial sum to out[0] with an fp32 atomic (order varies from run to run).  chunk_ws = n_chunks floats:
+ * the reproducible form -- every chunk stores its partial, one workgroup adds them in chunk order (clip_grad_norm_ under deterministic=True). */
+int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, float* chunk_ws, ocn_stream_t stream);
 
 /* ---- collectives (loss.py:23-54 gather_features and its backward) ------------------
  * Direct RCCL calls on the caller's stream (RCCL is bound at run time from the librccl.so the process has loaded; no link-time

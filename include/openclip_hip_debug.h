@@ -19,7 +19,8 @@ extern "C" {
  *   bits 8..   developer knobs of the persistent NT kernel: (v >> 8) & 1 skip GELU arithmetic (results wrong), & 2 / & 8 flip the
  *              epilogue's store / load cache policy, & 4 drain stores per tile, & 16 non-temporal A-operand loads, & 32 / & 128 drop the
  *              epilogue's stores / operand loads (results wrong), & 64 timeline build, & 0x200000 whole tail tiles instead of half tiles,
- *              & 0x400000 GELU arithmetic by the polynomial normal CDF (gelu_both_poly4; same tolerances, tests/test_dev_build_gpu.py);
+ *              & 0x400000 GELU arithmetic by the Abramowitz-Stegun erfc form that shipped until round 4 (gelu_both_as; the product uses the polynomial
+ *                         normal CDF gelu_both_poly4; same tolerances, tests/test_dev_build_gpu.py);
  *              (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off).
  *              The knobs of this group that live INSIDE the kernel exist in the developer build only (libopenclip_hip_dev.so:
  *              python -m open_clip_amd.build --dev, -DOCN_DEV_BUILD; select it with OCN_LIB_PATH): the product library compiles none of

@@ -59,7 +59,7 @@ SIGNATURES = {
     "ocn_sumsq_accum": [_p, _l, _p, _p],
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
     "ocn_adamw_multi": [_p, _p, _i, _f, _f, _f, _p, _f, _p],
-    "ocn_sumsq_multi": [_p, _p, _i, _p, _p],
+    "ocn_sumsq_multi": [_p, _p, _i, _p, _p, _p],
     "ocn_comm_unique_id": [_p],
     "ocn_comm_init": [_p, _i, _i, _p],
     "ocn_comm_destroy": [_p],
@@ -83,6 +83,8 @@ DEBUG_SIGNATURES = {
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_det_workspace_bytes": ([_i, _i, _i], _l),
             "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l)}
 
+ABI_VERSION = 102  # == OCN_ABI_VERSION of include/openclip_hip.h (tests/test_cabi.py compares the two): load() refuses any other library
+
 _lib = None
 _lock = threading.Lock()
 
@@ -103,6 +105,10 @@ def load():
         import torch  # noqa: F401  -- BEFORE the CDLL: the library must bind to the HIP runtime torch has loaded (its bundled
         #                 libamdhip64), not pull a second copy from /opt/rocm that knows no device ("no ROCm-capable device")
         lib = ctypes.CDLL(LIB_PATH)
+        lib.ocn_version.argtypes, lib.ocn_version.restype = [], _i
+        if lib.ocn_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports C-ABI version {lib.ocn_version()}, this package binds version {ABI_VERSION} "
+                               "(include/openclip_hip.h): rebuild it with `python -m open_clip_amd.build` -- argument lists differ between versions")
         for name, argtypes in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.argtypes = argtypes

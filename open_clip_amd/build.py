@@ -35,14 +35,13 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
     """``dev=True`` builds ``libopenclip_hip_dev.so`` with -DOCN_DEV_BUILD: the same library plus the in-kernel developer knobs of
     include/openclip_hip_debug.h (ablation bits, per-tile timeline, cache-policy flips) that tools/ select through ``OCN_LIB_PATH``;
     the product library compiles none of them."""
-    global OBJ, LIB, FLAGS
     if dev:
-        saved = (OBJ, LIB, FLAGS)
-        OBJ, LIB, FLAGS = os.path.join(CSRC, "_build", "dev"), os.path.join(HERE, "libopenclip_hip_dev.so"), FLAGS + ["-DOCN_DEV_BUILD"]
-        try:
-            return build(force=force, verbose=verbose)
-        finally:
-            OBJ, LIB, FLAGS = saved
+        return _build(force, verbose, os.path.join(CSRC, "_build", "dev"), os.path.join(HERE, "libopenclip_hip_dev.so"), FLAGS + ["-DOCN_DEV_BUILD"])
+    return _build(force, verbose, OBJ, LIB, FLAGS)
+
+
+def _build(force, verbose, OBJ, LIB, FLAGS):
+    """one library from every csrc/*.hip: object directory, output file and flags are arguments (no module state is touched: re-entrant)"""
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "openclip_hip.h"), os.path.abspath(__file__)]
     os.makedirs(OBJ, exist_ok=True)

@@ -14,7 +14,7 @@ void ocn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ocn_last_error(void) { return g_err; }
-extern "C" int ocn_version(void) { return 101; }
+extern "C" int ocn_version(void) { return OCN_ABI_VERSION; }
 
 // developer tuning / ablation knobs (process-global; timing experiments only)
 int g_ocn_tuning[16] = {0};

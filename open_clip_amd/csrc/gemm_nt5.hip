@@ -298,13 +298,24 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         if (IS_DGELU) v = v * dgelu_unpack4(dq[hb][g]);  // gelu'(pre-activation), saved by the forward epilogue
                         if (IS_GELU) {
                             f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
-                            if (ABL(a, 0x400000) && EPI == OCN_EPI_BIAS_GELU) {  // developer knob: polynomial-CDF form (ocn_common.h)
-                                gelu_both_poly4(v, gv, dv);
+                            if constexpr (EPI == OCN_EPI_BIAS_GELU) {
+#ifdef OCN_DEV_BUILD
+                                if (ABL(a, 0x400000)) {  // developer knob: the Abramowitz-Stegun form that shipped until round 4 (A/B)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float g1, d1;
+                                        gelu_both_as(v[e], g1, d1);
+                                        gv[e] = g1;
+                                        dv[e] = d1;
+                                    }
+                                } else
+#endif
+                                if (!ABL(a, 1)) gelu_both_poly4(v, gv, dv);  // polynomial-CDF form on the register quad (ocn_common.h)
                             } else if (!ABL(a, 1)) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     float g1, d1;
-                                    act_both<EPI == OCN_EPI_BIAS_QUICKGELU>(v[e], g1, d1);
+                                    quickgelu_both(v[e], g1, d1);
                                     gv[e] = g1;
                                     dv[e] = d1;
                                 }

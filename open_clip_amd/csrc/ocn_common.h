@@ -72,38 +72,16 @@ OCN_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mf
 // row of accumulator register `reg` (0..15) of a 32x32 MFMA result for this lane; column = lane & 31
 OCN_DEV int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// erf-GELU (nn.GELU(), reference transformer.py:295-299) and its derivative.  The GEMM epilogue that applies it is VALU-issue bound with
-// every MFMA pipe idle (0.21 ms of the 1.18 ms c_fc GEMM at batch 4096: profiles/r02_nt6_trickled_epilogue_experiment.txt), so the
-// operation count is what matters: erfc by Abramowitz-Stegun 7.1.25 (three terms, |abs err| <= 2.5e-5 -- 1/80 of the bf16 resolution of
-// the stored result) with the 1/2 of Phi folded into the coefficients and the argument scaling folded into the constants:
-// 13 plain VALU operations + v_exp_f32 + v_rcp_f32 per element for gelu AND gelu' (shared parts evaluated once).
-//   h(x) = erfc(|x|/sqrt 2) / 2 = t (a1 + t (a2 + t a3)) / 2 * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt 2)
-//   Phi(x) = 1/2 + copysign(1/2 - h, x);   gelu = x Phi;   gelu' = Phi + x exp(-x^2/2) / sqrt(2 pi)
-OCN_DEV void gelu_parts(float x, float& cdf, float& e) {
-    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.47047f * 0.70710678118654752f, 1.0f));
-    e = __builtin_amdgcn_exp2f(-0.72134752044448170f * (x * x));  // exp(-x^2/2)
-    float p = fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f);
-    p = fmaf(p, t, 0.5f * 0.3480242f);
-    const float h = p * t * e;
-    cdf = 0.5f + __builtin_copysignf(0.5f - h, x);
-}
-OCN_DEV float gelu_f(float x) {
-    float cdf, e;
-    gelu_parts(x, cdf, e);
-    return x * cdf;
-}
-// gelu(x) and gelu'(x) from ONE evaluation of the shared parts (forward GELU epilogue: the derivative is what gets saved)
-OCN_DEV void gelu_both(float x, float& g, float& dg) {
-    float cdf, e;
-    gelu_parts(x, cdf, e);
-    g = x * cdf;
-    dg = fmaf(x * 0.39894228040143268f, e, cdf);
-}
-// Developer-build alternative of gelu_both for a register quad (selected by a developer knob of the NT GEMM; NOT in the product library until it has
-// been measured on the GPU): the normal CDF as an odd polynomial, Phi(x) - 1/2 = x Q(x^2) on |x| <= 4.25 with x clamped beyond (Phi(4.25) = 1 - 1.07e-5),
-// nine coefficients from tools/gelu_poly_fit.py (weighted minimax; |Phi error| <= 1.24e-5 in fp32, half of gelu_parts' 2.5e-5; tests/test_gelu_poly.py).
-// No v_rcp_f32, no copysign, and every plain operation is a <4 x float> one that gfx950 issues as two v_pk_*_f32: 12.5 VALU issue slots per element
-// (8 packed fma of the Horner chain = 4, clamp 1, v_exp_f32 = 4, seven more packed operations = 3.5) against 17.4 for gelu_both as compiled.
+// erf-GELU (nn.GELU(), reference transformer.py:295-299) and its derivative, gelu(x) AND gelu'(x) from one evaluation of the shared parts (the
+// forward GELU epilogue saves the derivative for the backward).  The GEMM epilogue that applies it is VALU-issue bound with every MFMA pipe idle
+// (0.17-0.21 ms of the 1.1 ms c_fc GEMM at batch 4096: profiles/r02_nt6_trickled_epilogue_experiment.txt), so the issue-slot count is what matters.
+//   Phi(x) - 1/2 = x Q(x^2) on |x| <= 4.25, x clamped beyond (Phi(4.25) = 1 - 1.07e-5): the normal CDF as an ODD POLYNOMIAL, nine coefficients from
+//   tools/gelu_poly_fit.py (weighted minimax; |Phi error| <= 1.24e-5 in fp32 -- 1/160 of the bf16 resolution of the stored result; the coefficients
+//   in this header are checked against erf in float64 by tests/test_gelu_poly.py);  gelu = x Phi;  gelu' = Phi + x exp(-x^2/2) / sqrt(2 pi).
+// No v_rcp_f32, no copysign; on a register quad every plain operation is a <4 x float> one that gfx950 issues as two v_pk_*_f32: 18.9 static VALU
+// slots per element of the GELU kernel against 23.2 for the Abramowitz-Stegun 7.1.25 erfc form that shipped until round 4 (now `gelu_both_as`,
+// developer build only).  Adopted in round 5 after the kernel suite ran on it: -2.0 / -2.7 % on the two c_fc + GELU GEMMs
+// (profiles/r04_dev_polynomial_gelu_ab.txt).
 OCN_DEV void gelu_both_poly4(f32x4 x, f32x4& g, f32x4& dg) {
     f32x4 xc;
 #pragma unroll
@@ -125,13 +103,39 @@ OCN_DEV void gelu_both_poly4(f32x4 x, f32x4& g, f32x4& dg) {
     g = x * cdf;
     dg = (xc * 0.39894228040143268f) * e + cdf;
 }
+// one element, the same polynomial (the general fallback GEMM's epilogue: small / ragged shapes)
+OCN_DEV void gelu_both(float x, float& g, float& dg) {
+    f32x4 gv, dv;
+    gelu_both_poly4((f32x4){x, x, x, x}, gv, dv);
+    g = gv[0];
+    dg = dv[0];
+}
+#ifdef OCN_DEV_BUILD
+// the form that shipped until round 4 (A/B knob of the developer build): erfc by Abramowitz-Stegun 7.1.25, |abs err| <= 2.5e-5;
+//   h(x) = erfc(|x|/sqrt 2) / 2 = t (a1 + t (a2 + t a3)) / 2 * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt 2);  Phi(x) = 1/2 + copysign(1/2 - h, x)
+OCN_DEV void gelu_both_as(float x, float& g, float& dg) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.47047f * 0.70710678118654752f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * (x * x));  // exp(-x^2/2)
+    float p = fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f);
+    p = fmaf(p, t, 0.5f * 0.3480242f);
+    const float h = p * t * e;
+    const float cdf = 0.5f + __builtin_copysignf(0.5f - h, x);
+    g = x * cdf;
+    dg = fmaf(x * 0.39894228040143268f, e, cdf);
+}
+#endif
 // The derivative saved for the backward (aux of OCN_EPI_BIAS_GELU / OCN_EPI_DGELU) is stored in 8 bits: gelu'(x) lies in
 // [-0.1290, 1.1290], q = round((gelu' + 0.13) * 200) in [0, 252], gelu' ~ q / 200 - 0.13 with |error| <= 0.0025 (uniform, unbiased;
 // rms 0.0014 -- what rounding a value in [0.5, 1) to bf16 costs).  Half the bytes of a bf16 copy in the forward epilogue's second
 // output and in the backward epilogue's operand load.  The rounding is done by the fp32 adder: x * 200 + (2^23 + 26) has its integer
 // part in the low mantissa bits (round-to-nearest-even), so the low byte of the result's bit pattern IS q.
 constexpr float OCN_DGELU_SCALE = 200.0f, OCN_DGELU_OFFSET = 0.13f;
-OCN_DEV unsigned dgelu_q_bits(float d) { return __builtin_bit_cast(unsigned, fmaf(d, OCN_DGELU_SCALE, 8388608.0f + OCN_DGELU_OFFSET * OCN_DGELU_SCALE)); }
+// (the code is clamped to [0, 255] in the float domain -- one v_med3_f32: gelu' / QuickGELU' stay inside [0, 252] by construction, a pre-activation that
+// is NaN / Inf or any future activation must not wrap around in the low byte)
+OCN_DEV unsigned dgelu_q_bits(float d) {
+    const float r = fmaf(d, OCN_DGELU_SCALE, 8388608.0f + OCN_DGELU_OFFSET * OCN_DGELU_SCALE);
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_fmed3f(r, 8388608.0f, 8388608.0f + 255.0f));
+}
 OCN_DEV unsigned dgelu_pack4(float d0, float d1, float d2, float d3) {
     const unsigned q0 = dgelu_q_bits(d0), q1 = dgelu_q_bits(d1), q2 = dgelu_q_bits(d2), q3 = dgelu_q_bits(d3);
     // v_perm_b32: byte i of the result = byte sel[i] of {S0 (4..7), S1 (0..3)}
@@ -154,12 +158,6 @@ OCN_DEV void quickgelu_both(float x, float& g, float& dg) {
 template <bool QUICK>
 OCN_DEV void act_both(float x, float& g, float& dg) {
     if (QUICK) quickgelu_both(x, g, dg); else gelu_both(x, g, dg);
-}
-
-OCN_DEV float dgelu_f(float x) {
-    float cdf, e;
-    gelu_parts(x, cdf, e);
-    return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
 // bijective XCD-aware remap of a linear workgroup id: hardware places block b on XCD b % 8, so give

@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamEntry* __res
 }
 
 // out[0] += sum over every tensor of g^2 (same entry / chunk tables as adamw_multi_kernel)
+// chunk_ws != nullptr: the reproducible form -- the chunk's partial is stored to its own slot, sumsq_fold_kernel adds the slots in order
 __global__ __launch_bounds__(256) void sumsq_multi_kernel(const AdamEntry* __restrict__ entries, const int2* __restrict__ chunks,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float* __restrict__ chunk_ws) {
     __shared__ float red[4];
     const int2 ch = chunks[blockIdx.x];
     const AdamEntry e = entries[ch.x];
@@ -213,7 +214,22 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const AdamEntry* __res
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (chunk_ws) chunk_ws[blockIdx.x] = t; else unsafeAtomicAdd(out, t);
+    }
+}
+
+// out[0] += sum of ws[0 .. n) in ONE fixed order: thread t adds ws[t], ws[t + 256], ... ; the 256 partials fold through the wave butterflies and
+// four LDS slots (the same additions in the same order in every run)
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ ws, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += ws[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 int grid_for(long items, int block) {
@@ -277,10 +293,14 @@ extern "C" int ocn_adamw_multi(const void* entries, const void* chunks, int n_ch
     return OCN_OK;
 }
 
-extern "C" int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, ocn_stream_t stream) {
+extern "C" int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float* out, float* chunk_ws, ocn_stream_t stream) {
     OCN_CHECK_ARG(entries && chunks && out && n_chunks > 0, "ocn_sumsq_multi: bad arguments");
     hipLaunchKernelGGL(sumsq_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)entries,
-                       (const int2*)chunks, out);
+                       (const int2*)chunks, out, chunk_ws);
     OCN_CHECK_LAUNCH("ocn_sumsq_multi");
+    if (chunk_ws) {
+        hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, chunk_ws, n_chunks, out);
+        OCN_CHECK_LAUNCH("ocn_sumsq_multi (fold)");
+    }
     return OCN_OK;
 }

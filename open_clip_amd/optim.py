@@ -42,9 +42,12 @@ def weight_caches_of(model):
 
 class NativeAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2, grad_clip_norm=None, weight_caches=(),
-                 fused=True):
+                 fused=True, deterministic=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_clip_norm = grad_clip_norm
+        # the squared gradient norm of ``grad_clip_norm`` summed in a fixed order (per-chunk partials folded by one workgroup) instead of with
+        # fp32 atomics: the optimizer's share of NativeCLIP(deterministic=True) -- the clipped update is then bit-reproducible too
+        self.deterministic = bool(deterministic)
         self.weight_caches = list(weight_caches)
         self.fused = fused
         self._plan_key = None
@@ -186,7 +189,9 @@ class NativeAdamW(torch.optim.Optimizer):
         gn, max_norm = 0, 0.0
         if self.grad_clip_norm is not None:
             acc = torch.zeros(1, dtype=torch.float32, device=plan["entries_dev"].device)
-            _lib.call("ocn_sumsq_multi", plan["entries_dev"].data_ptr(), plan["chunks_dev"].data_ptr(), plan["n_chunks"], acc.data_ptr(), stream)
+            ws = torch.empty(plan["n_chunks"], dtype=torch.float32, device=acc.device) if self.deterministic else None
+            _lib.call("ocn_sumsq_multi", plan["entries_dev"].data_ptr(), plan["chunks_dev"].data_ptr(), plan["n_chunks"], acc.data_ptr(),
+                      0 if ws is None else ws.data_ptr(), stream)
             self.last_grad_norm_sq = acc
             gn, max_norm = acc.data_ptr(), float(self.grad_clip_norm)
         _lib.call("ocn_adamw_multi", plan["entries_dev"].data_ptr(), plan["chunks_dev"].data_ptr(), plan["n_chunks"], float(b1), float(b2),

@@ -44,7 +44,8 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_library_loads_and_reports_errors(lib_path):
     from open_clip_amd import _lib
     lib = _lib.load()
-    assert lib.ocn_version() >= 100
+    hdr = int(re.search(r"#define OCN_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.ocn_version() == hdr == _lib.ABI_VERSION  # header == library == ctypes table: load() refuses any other library
     # argument validation happens on the host before any launch: safe without a GPU
     with pytest.raises(RuntimeError, match="K=48 must be a multiple of 32"):
         _lib.call("ocn_gemm_nt", 0, 16, 48, 16, 48, 16, 64, 8, 64, 48, 0, 0, 0, 1.0, 0)

@@ -9,13 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEVLIB = os.path.join(ROOT, "open_clip_amd", "libopenclip_hip_dev.so")
 
-_POLY_GELU = r'''
+_AS_GELU = r'''
 import sys, torch
 sys.path.insert(0, %r)
 from open_clip_amd import _lib, ops
 from tests.test_kernels_gpu import bf, check, check_saved_derivative
 dev = torch.device("cuda:0")
-_lib.call("ocn_set_gemm_variant", (0x400000 << 8) | 5)  # persistent NT kernel, polynomial-CDF GELU arithmetic
+_lib.call("ocn_set_gemm_variant", (0x400000 << 8) | 5)  # persistent NT kernel, the Abramowitz-Stegun GELU arithmetic that shipped until round 4
 for M, N, K in [(2500, 768, 1024), (4096, 3072, 768), (1000, 640, 320)]:
     g = torch.Generator().manual_seed(M + N)
     a = bf(torch.randn(M, K, generator=g)).to(dev)
@@ -26,18 +26,20 @@ for M, N, K in [(2500, 768, 1024), (4096, 3072, 768), (1000, 640, 320)]:
     pre = (a.float() @ b.float().t() + bias).requires_grad_(True)
     act = torch.nn.functional.gelu(pre)
     act.backward(torch.ones_like(act))
-    check(f"dev gemm_nt[{M}x{N}x{K}] gelu(poly).out", out, act.detach(), bf16_out=True, abs_tol=1e-3)
-    check_saved_derivative(f"dev gemm_nt[{M}x{N}x{K}] gelu(poly).saved_derivative", aux, pre.grad)
-print("POLY_GELU_OK")
+    check(f"dev gemm_nt[{M}x{N}x{K}] gelu(A&S).out", out, act.detach(), bf16_out=True, abs_tol=1e-3)
+    check_saved_derivative(f"dev gemm_nt[{M}x{N}x{K}] gelu(A&S).saved_derivative", aux, pre.grad)
+print("AS_GELU_OK")
 '''
 
 
 @pytest.mark.gpu
-def test_polynomial_gelu_epilogue_of_the_developer_build():
-    """knob 0x400000 of the persistent NT GEMM (csrc/ocn_common.h::gelu_both_poly4: normal CDF as an odd polynomial, reference nn.GELU(),
-    transformer.py:295-299): output within the bf16 bound and the saved 8-bit derivative within half a step of torch's, like the shipped form"""
+def test_abramowitz_stegun_gelu_epilogue_of_the_developer_build():
+    """knob 0x400000 of the persistent NT GEMM in the developer build (csrc/ocn_common.h::gelu_both_as: the erfc form that shipped until round 4,
+    kept for A/B timing against the polynomial-CDF form the product library now uses; reference nn.GELU(), transformer.py:295-299): output within
+    the bf16 bound and the saved 8-bit derivative within half a step of torch's, like the shipped form (whose own checks are
+    tests/test_kernels_gpu.py / tests/test_gemm_bench_shapes_gpu.py on the product library)"""
     if not os.path.exists(DEVLIB):
         pytest.skip("developer library not built (python -m open_clip_amd.build --dev)")
     env = dict(os.environ, OCN_LIB_PATH=DEVLIB)
-    r = subprocess.run([sys.executable, "-c", _POLY_GELU % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0 and "POLY_GELU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    r = subprocess.run([sys.executable, "-c", _AS_GELU % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "AS_GELU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,6 +1,7 @@
-"""The polynomial normal CDF of the developer-build GELU epilogue (``gelu_both_poly4``, open_clip_amd/csrc/ocn_common.h; reference arithmetic:
-nn.GELU(), src/open_clip/transformer.py:295-299): the coefficients IN THE HEADER, evaluated the way the kernel does (fp32, one rounding per fma,
-argument clamped to +-4.25), against erf in float64.  CPU only -- the kernel path itself is selected by a developer knob and measured on the GPU."""
+"""The polynomial normal CDF of the GELU epilogue (``gelu_both_poly4``, open_clip_amd/csrc/ocn_common.h -- the product library's GELU arithmetic
+since round 5; reference arithmetic: nn.GELU(), src/open_clip/transformer.py:295-299): the coefficients IN THE HEADER, evaluated the way the kernel
+does (fp32, one rounding per fma, argument clamped to +-4.25), against erf in float64.  CPU only -- the kernels that use it are checked against
+torch on the GPU (tests/test_kernels_gpu.py, tests/test_gemm_bench_shapes_gpu.py)."""
 import os
 import re
 
@@ -42,7 +43,7 @@ def test_polynomial_cdf_of_the_header_is_within_its_stated_error():
     phi_true = 0.5 * (1.0 + erf(x64 / np.sqrt(2.0)))
     g_true = x64 * phi_true
     dg_true = phi_true + x64 * np.exp(-0.5 * x64 * x64) / np.sqrt(2.0 * np.pi)
-    assert np.abs(cdf - phi_true).max() <= 1.3e-5                     # header: <= 1.24e-5 (gelu_parts, the shipped form: 2.5e-5)
+    assert np.abs(cdf - phi_true).max() <= 1.3e-5                     # header: <= 1.24e-5 (the Abramowitz-Stegun form it replaced: 2.5e-5)
     assert np.abs(g - g_true).max() <= 1.3e-5 * 12.0 and np.abs(g - g_true)[np.abs(x) <= 4.25].max() <= 6e-5
     assert np.abs(dg - dg_true).max() <= 5e-5                          # the saved derivative is then quantised in steps of 5e-3
     assert cdf.min() >= -1.3e-5 and cdf.max() <= 1.0 + 1.3e-5
