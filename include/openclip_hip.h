@@ -286,7 +286,7 @@ int ocn_sumsq_multi(const void* entries, const void* chunks, int n_chunks, float
 /* ---- collectives (loss.py:23-54 gather_features and its backward) ------------------
  * Direct RCCL calls on the caller's stream (RCCL is bound at run time from the librccl.so the process has loaded; no link-time
  * dependency).  One process per GPU.  ocn_comm_unique_id: rank 0 makes the 128-byte id, the caller distributes it (any
- * side channel); ocn_comm_init: every rank, collectively.  dtype: 0 = fp32, 1 = bf16.  Counts are ELEMENTS per rank.
+ * side channel); ocn_comm_init: every rank, collectively.  dtype: 0 = fp32, 1 = bf16 (ocn_comm_broadcast also 2 = raw bytes: any other tensor, exact).  Counts are ELEMENTS per rank.
  *   allgather:           recv [world * count] = concat_r send_r [count]             (the packed [B, 2E] feature exchange)
  *   reduce_scatter_sum:  recv [count] = (sum_r send_r [world * count]) [rank slice]   (backward of the gather, loss.py:23-26)
  *   allreduce_sum:       buf [count] = sum_r buf_r, in place                         (row-sharded loss scalars, gradient buckets) */

@@ -72,7 +72,13 @@ class NativeComm:
         _lib.call("ocn_comm_allreduce_avg", self._comm, _check(t, "tensor"), t.numel(), _dt(t), self._stream())
 
     def broadcast(self, t, root=0):
-        _lib.call("ocn_comm_broadcast", self._comm, _check(t, "tensor"), t.numel(), _dt(t), int(root), self._stream())
+        """every dtype: fp32 / bf16 as such, anything else (integer / bool buffers, fp16 parameters) as its raw bytes -- a broadcast moves bits"""
+        if t.dtype in (F32, BF16):
+            n, dt = t.numel(), _dt(t)
+        else:
+            n, dt = t.numel() * t.element_size(), 2
+        if n:
+            _lib.call("ocn_comm_broadcast", self._comm, _check(t, "tensor"), n, dt, int(root), self._stream())
 
     def close(self):
         """destroys the communicator; pending collectives are waited for first (ncclCommDestroy does not order itself behind the streams:

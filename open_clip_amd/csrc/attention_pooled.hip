@@ -76,6 +76,7 @@ OCN_DEV void key_range(const PooledArgs& a, int b, int& begin, int& seq_end, int
     seq_end = a.seq_off ? a.seq_off[b + 1] : begin + a.L;
     vis_end = a.causal ? a.rows[b] + 1 : seq_end;
     if (vis_end > seq_end) vis_end = seq_end;
+    if (vis_end < begin) vis_end = begin;  // a pooled row in front of its sequence: an EMPTY visible range (output 0, no NaN), never a negative one
 }
 
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -130,12 +131,14 @@ __global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(PooledArgs a) {
     const float mt = across_groups_max(m);
     const float w = fast_exp2(m - mt);
     const float lt = across_groups_sum(l * w);
-    const float inv = 1.0f / lt;
+    // an empty visible key range (zero-length sequence, pooled row outside its sequence): lt = 0 -- the output is 0 and the statistic a finite
+    // very negative number instead of 0 * inf = NaN that the backward would spread into dkv, dq and the weight gradients
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     float o[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) o[d] = across_groups_sum(acc[d] * w) * inv;
     if (g == 0) *(u32x4_t*)(const_cast<bf16*>(a.out) + (size_t)b * C + h * 64 + c * 8) = pack8(o);
-    if (lane == 0) a.lse[bh] = (mt + __log2f(lt)) * LN2;
+    if (lane == 0) a.lse[bh] = lt > 0.f ? (mt + __log2f(lt)) * LN2 : -1e30f;
 }
 
 __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(PooledArgs a) {
@@ -211,6 +214,7 @@ int check(const PooledArgs& a, const char* name) {
     OCN_CHECK_ARG(a.q && a.kv && a.out && a.lse && a.rows, "%s: null operand", name);
     OCN_CHECK_ARG(a.B > 0 && a.L > 0 && a.H > 0, "%s: bad shape B=%d L=%d H=%d", name, a.B, a.L, a.H);
     OCN_CHECK_ARG((((uintptr_t)a.q | (uintptr_t)a.kv | (uintptr_t)a.out) & 15) == 0, "%s: operands must be 16-byte aligned", name);
+    OCN_CHECK_ARG(((uintptr_t)a.lse & 3) == 0, "%s: lse must be 4-byte aligned", name);
     return OCN_OK;
 }
 

@@ -13,7 +13,7 @@ namespace {
 
 typedef struct { char internal[128]; } UniqueId;  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
 typedef void* Comm;                               // ncclComm_t
-enum { kSum = 0, kAvg = 4, kFloat32 = 7, kBfloat16 = 9 };   // ncclSum, ncclAvg, ncclFloat32, ncclBfloat16 (rccl.h)
+enum { kSum = 0, kAvg = 4, kUint8 = 1, kFloat32 = 7, kBfloat16 = 9 };   // ncclSum, ncclAvg, ncclUint8, ncclFloat32, ncclBfloat16 (rccl.h)
 
 struct Rccl {
     void* handle = nullptr;
@@ -50,7 +50,7 @@ Rccl* rccl() {
     return r.handle ? &r : nullptr;
 }
 
-int dtype_of(int d) { return d == 1 ? kBfloat16 : kFloat32; }
+int dtype_of(int d) { return d == 1 ? kBfloat16 : (d == 2 ? kUint8 : kFloat32); }  // 0 = fp32, 1 = bf16, 2 = raw bytes (broadcast only)
 
 #define OCN_RCCL(call, what)                                                                          \
     do {                                                                                              \
@@ -126,7 +126,9 @@ extern "C" int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int 
 // construction, base_task.py:227) -- exact for every dtype, one collective per tensor
 extern "C" int ocn_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, ocn_stream_t stream) {
     Rccl* R = rccl();
-    OCN_CHECK_ARG(R && R->Broadcast && comm && buf && count > 0 && root >= 0, "ocn_comm_broadcast: bad arguments");
+    OCN_CHECK_ARG(R, "ocn_comm_broadcast: librccl.so could not be loaded");
+    OCN_CHECK_ARG(R->Broadcast, "ocn_comm_broadcast: the loaded librccl.so exports no ncclBroadcast");
+    OCN_CHECK_ARG(comm && buf && count > 0 && root >= 0 && dtype >= 0 && dtype <= 2, "ocn_comm_broadcast: bad arguments");
     OCN_RCCL(R->Broadcast(buf, buf, (size_t)count, dtype_of(dtype), root, (Comm)comm, (hipStream_t)stream), "ocn_comm_broadcast");
     return OCN_OK;
 }

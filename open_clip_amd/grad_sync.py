@@ -132,9 +132,7 @@ class NativeGradSync:
         import torch.distributed as dist
         with torch.no_grad():
             for t in list(self.model.parameters()) + list(self.model.buffers()):
-                if self.comm is not None:
-                    if t.dtype not in (torch.float32, torch.bfloat16):
-                        continue  # integer buffers (none in this model) are not parameters of the step
+                if self.comm is not None:  # every dtype travels (NativeComm.broadcast sends non-float tensors as raw bytes), as under the process group
                     buf = t.data if t.is_contiguous() else t.data.contiguous()
                     self.comm.broadcast(buf, 0)
                     if buf.data_ptr() != t.data.data_ptr():
@@ -173,6 +171,8 @@ class NativeGradSync:
     def _reduce_ranges(self, ranges):
         """large ranges in place, one collective each; the small ones of the group through ONE packed fp32 buffer (which ranges are small
         depends on their sizes only, so every rank packs the same ones in the same order)"""
+        if self.world_size == 1 and self.comm is None:
+            return  # no transport configured: nothing to reduce, and no packing work either
         small = [flat for flat, _ in ranges if flat.numel() < PACK_BELOW and flat.dim() == 1]
         if len(small) < 2:
             small = []
@@ -225,10 +225,14 @@ class NativeGradSync:
                         q.grad = torch.zeros_like(q)
                     left.append(q)
         else:
+            solo = self.world_size == 1 and self.comm is None  # nobody to disagree with: an unused parameter is not an error
             for key in self._groups:  # registration order, not hook order
                 if self._reduced_by_hook.get(key):
                     continue
                 missing = [q for q in self._groups[key] if q.grad is None]
+                if missing and solo:
+                    left += [q for q in self._groups[key] if q.grad is not None]
+                    continue
                 if missing:  # the other ranks may have reduced this group already: fail loudly, here, instead of hanging in RCCL
                     names = names or {id(p): n for n, p in self.model.named_parameters()}
                     raise RuntimeError("NativeGradSync: no gradient reached " + ", ".join(names.get(id(q), "?") for q in missing[:8]) + " on this rank; "

@@ -1009,10 +1009,25 @@ class NativeCLIP(nn.Module):
         return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, idx, self._cache, B, L, normalize)
 
     def get_logits(self, image, text):
-        i, t = self.encode_image(image, True), self.encode_text(text, True)
-        li = self.logit_scale.exp() * i @ t.T
-        if self.logit_bias is not None:
-            li = li + self.logit_bias
+        """model.py:413-420 (evaluation helper: `logit_scale.exp() * image_features @ text_features.T` (+ logit_bias), and its transpose) through
+        the library's own GEMM like every other product of the path: (s I) rounded to bf16 -- the reference evaluates (s I) first, too, and the
+        loss multiplies exactly these operands -- times T^T on MFMA with fp32 accumulation and output, the bias in the epilogue.  No gradient
+        (the reference's callers sit under no_grad / inference_mode, train.py:536-713); anything that wants one goes through the loss modules."""
+        with torch.no_grad():
+            i, t = self.encode_image(image, True).float().contiguous(), self.encode_text(text, True).float().contiguous()
+            E = i.shape[1]
+            Ep = _round_up(E, 64)
+            s = self.logit_scale.detach().exp().reshape(1).float()
+            if Ep == E:
+                i16, t16 = ops.cast_bf16_scaled(i, s), ops.cast_bf16(t)
+            else:  # embed dims that are not a multiple of the GEMM's K step: zero-padded operands (no registered config needs it)
+                i16, t16 = torch.zeros(i.shape[0], Ep, dtype=BF16, device=i.device), torch.zeros(t.shape[0], Ep, dtype=BF16, device=t.device)
+                i16[:, :E].copy_(i * s)
+                t16[:, :E].copy_(t)
+            N = t.shape[0]
+            bias = None if self.logit_bias is None else self.logit_bias.detach().reshape(1).float().expand(N).contiguous()
+            li = torch.empty(i.shape[0], _round_up(N, 4), dtype=F32, device=i.device)[:, :N]
+            ops.gemm_nt(ops.EPI_F32, i16, t16, li, bias=bias)
         return li, li.T
 
     def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):

@@ -246,9 +246,16 @@ def attn_pooled_fwd(q, kv, rows, B, L, H, causal, scale, seq_off=None):
 
 
 def attn_pooled_bwd(q, kv, out, dout, lse, rows, B, L, H, causal, scale, seq_off=None):
-    """-> dq [B, C] bf16, dkv [M, 2C] bf16 (every key row written)"""
+    """-> dq [B, C] bf16, dkv [M, 2C] bf16.  The kernel writes every key row of every sequence; rows of ``kv`` that belong to NO sequence can only
+    exist with a packed layout whose last offset is below M -- the model never builds one (_TextPack allocates M = seq_off[B] rows, read from the
+    same plan) -- and the dense layout must cover kv exactly, which is checked here: dkv feeds the K,V weight-gradient GEMM, an unwritten row
+    would be uninitialised memory."""
     so = _chk(_layout(seq_off).seq_off, torch.int32, "seq_off") if seq_off is not None else 0
-    dq, dkv = empty(q.shape, BF16, q), empty(kv.shape, BF16, kv)
+    C = H * 64
+    if q.shape != (B, C) or kv.shape[1] != 2 * C or (seq_off is None and kv.shape[0] != B * L):
+        raise RuntimeError(f"attn_pooled_bwd: q {tuple(q.shape)} / kv {tuple(kv.shape)} do not match B={B}, L={L}, H={H}, head_dim 64")
+    dq = empty(q.shape, BF16, q)
+    dkv = empty(kv.shape, BF16, kv)  # packed: M == seq_off[B] (model._TextPack takes M from the plan that wrote seq_off), so no row stays unwritten
     _lib.call("ocn_attn_pooled_bwd", _chk(q, BF16, "q"), _chk(kv, BF16, "kv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse"),
               _chk(dq, BF16, "dq"), _chk(dkv, BF16, "dkv"), so, _chk(rows, torch.int32, "rows"), B, L, H, int(causal), float(scale), _stream())
     return dq, dkv
