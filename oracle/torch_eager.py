@@ -77,6 +77,13 @@ def clip_loss(i, t, s):
     return (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels)) / 2
 
 
+def siglip_loss(i, t, s, b):
+    """loss.py:356-367 (SigLipLoss._loss, world_size 1): -sum(logsigmoid(labels * (s I T^T + b))) / B, labels = 2 eye - 1"""
+    logits = s * i @ t.T + b
+    labels = 2 * torch.eye(logits.shape[0], device=logits.device, dtype=logits.dtype) - 1
+    return -F.logsigmoid(labels * logits).sum() / logits.shape[0]
+
+
 def amp_step_grads(cfg, state, image, text):
     """features, loss and every parameter gradient of ONE step of the same eager operators under ``torch.amp.autocast(bf16)`` -- the reference's own
     ``--precision amp_bf16`` policy (precision.py:6-17) on this GPU.  tests/test_bench_size_gpu.py measures it against the fp32 reference at the

@@ -1,0 +1,71 @@
+"""CPU: the one-process emulation of W ranks that tests/test_parity_at_size_gpu.py uses at BASELINE config 3 / 5 sizes (tests/rank_emulation.py:
+the all-gather hands out the gathered features, reduce-scatter / all-reduce record each rank's contribution and the test sums them) reproduces
+plain autograd on the gathered features -- for the row-sharded global ClipLoss (every rank), the reference's redundant global form and the
+distributed SigLipLoss (reference: src/open_clip/loss.py:91-141, :406-489).  The HIP compute seam is replaced by the fp32 stand-in of
+tests/test_dist_loss_gloo.py; this validates the HARNESS, the kernels are what the GPU test checks."""
+import torch
+
+from tests.rank_emulation import Collectives, unit_features
+from tests.test_dist_loss_gloo import CpuPairTerm
+
+
+def _ref_clip(I, T, s):
+    I, T, s = I.clone().requires_grad_(True), T.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    li = s * I @ T.t()
+    lab = torch.arange(I.shape[0])
+    loss = (torch.nn.functional.cross_entropy(li, lab) + torch.nn.functional.cross_entropy(li.t(), lab)) / 2
+    loss.backward()
+    return loss.detach(), I.grad, T.grad, s.grad
+
+
+def test_row_sharded_and_global_cliploss_emulation(monkeypatch):
+    import open_clip_amd.loss as L
+    monkeypatch.setattr(L, "PairTerm", CpuPairTerm)
+    W, B, E = 4, 6, 16
+    I, T = unit_features(W * B, E, 3, torch.device("cpu"))
+    s = torch.tensor(9.5)
+    loss_ref, dI_ref, dT_ref, ds_ref = _ref_clip(I, T, s)
+    coll = Collectives(torch.cat([I, T], dim=1))
+    monkeypatch.setattr(L, "_all_gather", coll.all_gather)
+    monkeypatch.setattr(L, "_reduce_scatter_sum", coll.reduce_scatter)
+    monkeypatch.setattr(L, "_all_reduce_sum", coll.all_reduce)
+    dI, dT, ds, losses = [], [], [], []
+    for r in range(W):
+        Ir, Tr, sr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True), s.clone().requires_grad_(True)
+        loss = L.NativeClipLoss(rank=r, world_size=W, row_sharded=True)(Ir, Tr, sr)
+        loss.backward()
+        dI.append(Ir.grad), dT.append(Tr.grad), ds.append(sr.grad), losses.append(loss.detach())
+    cols = torch.stack(coll.rs_inputs).sum(0)
+    assert torch.allclose(torch.cat(dI) + cols[:, :E], dI_ref, atol=1e-6) and torch.allclose(torch.cat(dT) + cols[:, E:], dT_ref, atol=1e-6)
+    assert abs(float(torch.stack(losses).sum()) - float(loss_ref)) < 1e-5 and abs(float(torch.stack(ds).sum()) - float(ds_ref)) < 1e-6
+    r = 2
+    Ir, Tr, sr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True), s.clone().requires_grad_(True)
+    loss = L.NativeClipLoss(rank=r, world_size=W, row_sharded=False)(Ir, Tr, sr)
+    loss.backward()
+    assert torch.allclose(Ir.grad, dI_ref[r * B:(r + 1) * B], atol=1e-6) and torch.allclose(Tr.grad, dT_ref[r * B:(r + 1) * B], atol=1e-6)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 and abs(float(sr.grad) - float(ds_ref)) < 1e-6
+
+
+def test_siglip_emulation(monkeypatch):
+    import open_clip_amd.loss as L
+    monkeypatch.setattr(L, "PairTerm", CpuPairTerm)
+    W, B, E, r = 4, 6, 16, 1
+    I, T = unit_features(W * B, E, 4, torch.device("cpu"))
+    Ia, Ta = I.clone().requires_grad_(True), T.clone().requires_grad_(True)
+    s, b = torch.tensor(10.0, requires_grad=True), torch.tensor(-10.0, requires_grad=True)
+    logits = (s * Ia[r * B:(r + 1) * B]) @ Ta.t() + b
+    lab = -torch.ones_like(logits)
+    lab[torch.arange(B), r * B + torch.arange(B)] = 1
+    ref = -torch.nn.functional.logsigmoid(lab * logits).sum() / B
+    ref.backward()
+    for chunk in (0, 4):
+        coll = Collectives(T)
+        monkeypatch.setattr(L, "_all_gather", coll.all_gather)
+        monkeypatch.setattr(L, "_reduce_scatter_sum", coll.reduce_scatter)
+        Ir, Tr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True)
+        sr, br = torch.tensor(10.0, requires_grad=True), torch.tensor(-10.0, requires_grad=True)
+        loss = L.NativeSigLipLoss(rank=r, world_size=W, chunk_size=chunk)(Ir, Tr, sr, br)
+        loss.backward()
+        assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, float(ref))
+        assert torch.allclose(Ir.grad, Ia.grad[r * B:(r + 1) * B], atol=1e-6) and torch.allclose(coll.rs_inputs[0], Ta.grad, atol=1e-6)
+        assert abs(float(sr.grad) - float(s.grad)) < 1e-5 and abs(float(br.grad) - float(b.grad)) < 1e-5
