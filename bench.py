@@ -7,8 +7,8 @@ WORLD_SIZE that is not N, or fewer visible GPUs than N, is an error, never a sil
 forward (both towers) -> ClipLoss (packed feature all-gather + global logits when N>1) -> backward (DDP bucketed
 grad all-reduce overlapped) -> AdamW step -> logit_scale clamp, on synthetic inputs already resident in HBM.
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel (the NT MFMA GEMM) from HIP events recorded
-around every one of its launches inside the timed region; ``cpu_baseline`` times the CPU oracle (port of the
-reference path) on the host cores for a bounded sample (N=1 only).
+around every one of its launches inside the timed region; ``cpu_baseline`` times the reference's own train_one_epoch
+(from oracle/_ref/reference_src.zip on the GPU box; the CPU oracle -- the port -- when that is missing) on the host cores for a bounded sample (N=1 only).
 """
 import argparse
 import json
@@ -71,8 +71,9 @@ def parse():
     ap.add_argument("--native-allreduce", action="store_true", help="gradient all-reduce WITHOUT DistributedDataParallel: per-block in-place all-reduce of the "
                     "backward's own gradient arenas from post-accumulate hooks (open_clip_amd/grad_sync.py; RCCL through the C ABI, or the process "
                     "group with --dist-backend gloo); with one process: a one-rank communicator (what the hooks and launches cost)")
-    ap.add_argument("--native-comm", action="store_true", help="N>1: the loss's feature all-gather / reduce-scatter through the C ABI's RCCL communicator "
-                    "(ocn_comm_*) instead of torch.distributed's process group")
+    ap.add_argument("--native-comm", action="store_true", help="the loss's feature all-gather / reduce-scatter / scalar all-reduce through the C ABI's RCCL communicator "
+                    "(ocn_comm_*) instead of torch.distributed's process group; with one process: a one-rank communicator -- the loss runs its distributed "
+                    "(row-sharded) form with identity collectives (what the marshalling and the extra launches cost)")
     ap.add_argument("--bucket-cap-mb", type=int, default=128)
     ap.add_argument("--data-ranks", type=int, default=1, help="developer: with one process, use the concatenation of the batches R ranks would "
                     "get (what a world_size-R run sees as its global batch; tests/test_bench_gpu.py)")
@@ -91,6 +92,8 @@ def parse():
     ap.add_argument("--no-dense-text-line", action="store_true", help="skip the extra --dense-text timing that the default line carries")
     ap.add_argument("--no-extra-lines", action="store_true", help="skip the two further samples the default line carries: `reference_work` (dense text tower AND "
                     "full last blocks: exactly the rows the reference executes) and `accum8_gbs32768` (the metric's own global batch on one GPU, --accum-freq 8)")
+    ap.add_argument("--no-config-lines", action="store_true", help="skip the two samples of BASELINE configs 4 / 5 (ViT-L-14 with block recompute; ViT-H-14 + SigLIP) "
+                    "that the default ViT-B-32 line carries as `config4_vitl14` / `config5_vith14_siglip` (each a subprocess of this file)")
     ap.add_argument("--dense-text", action="store_true", help="run all context_length positions of every caption through the text tower like the reference "
                     "does (default: packed -- only the tokens up to the pooled EOT exist; same features, loss and gradients, see model.py::_TextPack)")
     ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
@@ -181,7 +184,7 @@ def roof(a):
 
 
 def _reference_cpu_record():
-    """the reference's own train_one_epoch timed in the build container (oracle/ref_cpu_baseline.py; the GPU box has no /root/reference)"""
+    """the reference's own train_one_epoch timed in the build container in round 2 (kept beside the live number: another host)"""
     path = os.path.join(ROOT, "profiles", "r02_reference_cpu_train_one_epoch.json")
     if not os.path.exists(path):
         return None
@@ -190,11 +193,32 @@ def _reference_cpu_record():
             "what": r["what"], "oracle_port_same_process_pairs_per_s": r["oracle_port_same_process"]["pairs_per_s"]}
 
 
-def cpu_baseline(model_name, seconds=24.0):
-    """CPU oracle (port of the reference hot path) fwd+bwd+AdamW at the reference's CPU config (bs 32, fp32) on this box's host cores.
-    The thread count is chosen by a short sweep (one step each; batch 32 does not scale to every core of a large host), then a bounded
-    sample is timed at the best setting.  The reference's own loop cannot run here; its number from the build container, with the
-    port timed beside it there, is attached (``reference_in_build_container``)."""
+def _reference_cpu_live(threads, steps=8, timeout=240):
+    """the REFERENCE's own ``open_clip_train.train.train_one_epoch`` (train.py:337) on ITS ``CLIP`` + ``CLIPTask`` + AdamW, ViT-B-32 fp32
+    batch 32, on this box's host cores -- in a subprocess (``oracle/ref_cpu_baseline.py``; the reference's packages come from /root/reference or, on
+    the GPU box, from ``oracle/_ref/reference_src.zip``: oracle/fetch_ref.py).  None when neither is here or the run fails (the port stays)."""
+    import subprocess
+    import tempfile
+    if not (os.path.isdir("/root/reference/src/open_clip") or os.path.exists(os.path.join(ROOT, "oracle", "_ref", "reference_src.zip"))):
+        return None
+    out = os.path.join(tempfile.mkdtemp(prefix="ocn_refcpu_"), "ref.json")
+    cmd = [sys.executable, "-m", "oracle.ref_cpu_baseline", "--steps", str(steps), "--threads", str(threads), "--out", out, "--no-port"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        if r.returncode != 0 or not os.path.exists(out):
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.load(open(out))
+    except Exception as e:  # the baseline must never take the bench line down with it
+        return {"error": repr(e)[:300]}
+
+
+def cpu_baseline(model_name, seconds=12.0):
+    """The CPU baseline beside the native step, on this box's host cores, at the reference's CPU configuration (ViT-B-32 fp32, batch 32):
+    ``kind: "reference"`` -- the reference's own train_one_epoch (``_reference_cpu_live``), its pairs/s from the outer wall clock and from the
+    reference's own log line -- whenever the reference's packages are here; the CPU oracle (port of the reference path, fwd+bwd+AdamW) is timed
+    first either way: its short thread sweep picks the thread count (batch 32 does not scale to every core of a large host), its own pairs/s rides
+    along as ``port``, and it IS the baseline (``kind: "port"``) when the reference is not available."""
     from oracle import clip_oracle as O
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.synth import init_state_dict, synthetic_batch
@@ -222,20 +246,30 @@ def cpu_baseline(model_name, seconds=24.0):
         torch.set_num_threads(th)
         one()
         sweep[th] = round(one(), 3)
-        if time.time() - t_start > seconds * 0.6:
+        if time.time() - t_start > seconds:
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    times = []
-    while (time.time() - t_start < seconds or len(times) < 2) and len(times) < 8:
-        times.append(one())
-    warm = sorted(times)
-    med = warm[len(warm) // 2]
-    rec = {"value": round(bs / med, 2), "unit": "pairs/s", "cores": best, "host_cores": ncpu, "kind": "port",
-           "sample": f"{len(times)} steps of CPU-oracle fwd+bwd+AdamW, {model_name} fp32, batch {bs}, {best} threads (sweep s/step: {sweep}); median {med:.2f} s/step"}
-    ref = _reference_cpu_record()
-    if ref is not None:
-        rec["reference_in_build_container"] = ref
+    times = [one() for _ in range(3)]
+    med = sorted(times)[len(times) // 2]
+    port = {"value": round(bs / med, 2), "unit": "pairs/s", "cores": best, "host_cores": ncpu, "kind": "port",
+            "sample": f"{len(times)} steps of CPU-oracle fwd+bwd+AdamW, {model_name} fp32, batch {bs}, {best} threads (sweep s/step: {sweep}); median {med:.2f} s/step"}
+    ref = _reference_cpu_live(best) if model_name == "ViT-B-32" else None
+    if ref is not None and "pairs_per_s" in ref:
+        rec = {"value": ref["pairs_per_s"], "unit": "pairs/s", "cores": ref["torch_threads"], "host_cores": ref["nproc"], "kind": "reference",
+               "value_reference_log_line": ref.get("pairs_per_s_reference_log_line"),
+               "sample": f"{ref['steps']} steps of the reference's open_clip_train.train.train_one_epoch (train.py:337) on its own CLIP + CLIPTask + AdamW, ViT-B-32 fp32, "
+                         f"batch {bs}, world_size 1, {ref['torch_threads']} threads (chosen by the port's sweep), synthetic in-memory batches; median of the warm "
+                         f"steps {ref['sec_per_step_median_warm']:.2f} s/step by an outer wall clock; `value_reference_log_line` = median of the reference's own "
+                         f"console `N/s` (train.py:456); {ref['where']}",
+               "sec_per_step_all": ref.get("sec_per_step_all"), "port": port}
+    else:
+        rec = dict(port)
+        if ref is not None:
+            rec["reference_run_error"] = ref.get("error")
+    old = _reference_cpu_record()
+    if old is not None:
+        rec["reference_in_build_container_round2"] = old
     return rec
 
 
@@ -367,6 +401,59 @@ def main():
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, mine)
 
+    line = run(args, rank, local_rank, world, dev, rank_devices, one_device)
+    if line is not None:
+        # BASELINE configs 4 and 5 on the same line: after the timed ViT-B-32 steps and their baselines, with this process's HBM
+        # handed back first (run() has returned: model, optimizer and activations are gone), each in a process of its own
+        want = (world == 1 and args.model == "ViT-B-32" and not args.siglip and args.local_batch == 4096 and args.accum_freq == 1 and not args.h2d
+                and not args.grad_checkpointing and args.data_ranks == 1 and not args.no_config_lines and not args.no_extra_lines)
+        if want:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["config4_vitl14"] = config_line(["--model", "ViT-L-14", "--local-batch", "2048", "--grad-checkpointing"],
+                                                 "BASELINE config 4 on one GPU: ViT-L-14, local batch 2048 (gbs 16384 / 8), block recompute "
+                                                 "(--grad-checkpointing; --keep-blocks auto keeps what the free HBM holds), ClipLoss")
+            line["config5_vith14_siglip"] = config_line(["--model", "ViT-H-14", "--siglip", "--local-batch", "1024", "--grad-checkpointing"],
+                                                        "BASELINE config 5 on one GPU: ViT-H-14 + SigLipLoss, local batch 1024 (gbs 8192 / 8), block recompute")
+        print(json.dumps(line), flush=True)
+    if world > 1 or args.force_ddp:
+        torch.distributed.destroy_process_group()
+
+
+def config_line(extra_args, what, steps=4, warmup=1, timeout=420):
+    """one of the other BASELINE configurations through this same file in a subprocess (fresh HBM: --keep-blocks auto plans against what is free):
+    `steps` timed steps of which the first carries HIP events on every GEMM launch (its towers one at a time), so the record has the per-kernel
+    roofline of THAT model; returns the sub-record that rides on the default line, or {"error": ...} -- a sample never takes the line down"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-eager-baseline",
+           "--no-dense-text-line", "--no-extra-lines", "--no-clock-sample", "--no-config-lines"] + extra_args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or len(lines) != 1:
+            return {"error": (r.stderr or r.stdout)[-400:], "returncode": r.returncode}
+        d = json.loads(lines[0])
+        rf = d.get("roofline", {})
+        keep = ("kernel", "achieved", "bound", "frac", "frac_mfma", "frac_hbm", "launches", "avg_launch_ms", "share_of_gemm_time")
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "what": what,
+                "model_tflops_per_gpu": d.get("step_model_tflops_per_gpu", d.get("step_dense_equivalent_model_tflops_per_gpu")),
+                "mfu_of_2500_tflops": round((d.get("step_model_tflops_per_gpu") or d.get("step_dense_equivalent_model_tflops_per_gpu") or 0.0) / PEAK_BF16_TFLOPS, 4),
+                "local_batch": d["config"]["local_batch"], "grad_checkpointing": d["config"]["grad_checkpointing"], "final_loss": d["config"]["final_loss"],
+                "peak_hbm_gb": d.get("peak_hbm_gb_rank0"), "wall_s": round(time.perf_counter() - t0, 1),
+                "note": f"{steps} timed steps, the first event-timed with the towers one at a time (its GEMM launches carry HIP events: the roofline below); "
+                        "a sanity sample beside the headline metric, not the metric",
+                "roofline": {"dominant": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_mfma", "frac_hbm", "avg_launch_ms", "launches")},
+                             "by_kernel": [{k: e.get(k) for k in keep} for e in rf.get("by_kernel", [])[:8]],
+                             "all_gemm_launches": rf.get("all_gemm_launches"), "gemm_share_of_step": rf.get("gemm_share_of_step")}}
+    except Exception as e:
+        return {"error": repr(e)[:400]}
+
+
+def run(args, rank, local_rank, world, dev, rank_devices, one_device):
+    """the measured body: builds the model, times the K steps, the extra samples and the baselines; returns rank 0's JSON line (None elsewhere)"""
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.loss import NativeClipLoss
     from open_clip_amd.model import NativeCLIP
@@ -448,13 +535,13 @@ def main():
     if (args.native_allreduce or args.native_comm) and args.dist_backend == "nccl":
         from open_clip_amd.comm import NativeComm  # RCCL behind the C ABI; the 128-byte id travels through the process group once
         native_comm = NativeComm.from_process_group(rank, world) if world > 1 else NativeComm(NativeComm.make_unique_id(), 0, 1)
-    loss_comm = native_comm if (args.native_comm and world > 1) else None
+    loss_comm = native_comm if args.native_comm else None  # with one process: a one-rank communicator, the loss still runs its distributed form
     if args.siglip:
         from open_clip_amd.loss import NativeSigLipLoss
         loss_fn = NativeSigLipLoss(rank=rank, world_size=world, comm=loss_comm, deterministic=args.deterministic)
     else:
         loss_fn = NativeClipLoss(local_loss=False, gather_with_grad=False, rank=rank, world_size=world,
-                                 row_sharded=(world > 1 and not args.naive_global_loss), comm=loss_comm, deterministic=args.deterministic)
+                                 row_sharded=((world > 1 or loss_comm is not None) and not args.naive_global_loss), comm=loss_comm, deterministic=args.deterministic)
     opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=args.lr, betas=(0.9, 0.98), eps=1e-6, weight_caches=weight_caches_of(model))
     net = model
     grad_sync = None
@@ -621,6 +708,7 @@ def main():
             accum8 = {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
 
+    line = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = B * F_ACC * world / (elapsed / args.steps)
@@ -645,7 +733,7 @@ def main():
                        "ddp": bool((world > 1 or args.force_ddp) and grad_sync is None), "bucket_cap_mb": args.bucket_cap_mb,
                        "gradient_allreduce": ("native per-block in-place all-reduce (open_clip_amd/grad_sync.py)" + (" over RCCL through the C ABI" if native_comm is not None else " over the process group")
                                               if grad_sync is not None else ("DistributedDataParallel" if (world > 1 or args.force_ddp) else "none (one process)")),
-                       "loss_collectives": "C ABI (ocn_comm_*)" if loss_comm is not None else ("torch.distributed" if world > 1 else "none"),
+                       "loss_collectives": ("C ABI (ocn_comm_*)" + (" on a one-rank communicator" if world == 1 else "")) if loss_comm is not None else ("torch.distributed" if world > 1 else "none"),
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "text_tower": text_rows_note,
                        "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
@@ -754,13 +842,11 @@ def main():
             line["torch_eager_baseline"] = rec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model)
-        print(json.dumps(line), flush=True)
     if grad_sync is not None and rank == 0 and os.environ.get("OCN_BENCH_VERBOSE"):
         print("grad_sync stats:", {k: (v if not isinstance(v, list) else v[-30:]) for k, v in grad_sync.stats.items()}, file=sys.stderr)
     if native_comm is not None:
         native_comm.close()
-    if world > 1 or args.force_ddp:
-        torch.distributed.destroy_process_group()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -193,12 +193,15 @@ class _ClipLossFn(torch.autograd.Function):
         s = _device_scalar(logit_scale, dev)  # stays on the device: no host synchronisation inside the step
         B, E = I.shape
         acc = torch.zeros(2, dtype=F32, device=dev)  # [loss_sum, sum(G * logits) = s * dscale]
-        if world_size > 1:
+        # a communicator handed in with world_size 1 (bench.py --native-comm on one GPU, tests) still runs the distributed form: every collective is
+        # an identity then, but counts, dtypes and pointers travel the path a node's ranks use
+        use_dist = world_size > 1 or comm is not None
+        if use_dist:
             packed = torch.cat([I, T], dim=1)
             allp = torch.empty(world_size * B, 2 * E, dtype=F32, device=dev)
             _all_gather(allp, packed, comm)
             I_all, T_all = allp[:, :E].contiguous(), allp[:, E:].contiguous()
-        if world_size == 1:
+        if not use_dist:
             # loss.py:109-110: li = s I T^T, lt = s T I^T ; labels arange(B)
             ti = _term(I, T, s, deterministic).compute_logits()
             tt = _term(T, I, s, deterministic).compute_logits()
@@ -310,7 +313,8 @@ class _SigLipLossFn(torch.autograd.Function):
         s, b = _device_scalar(logit_scale, dev), _device_scalar(logit_bias, dev)
         B, E = I.shape
         acc = torch.zeros(3, dtype=F32, device=dev)  # loss, dscale, dbias
-        if world_size > 1:
+        use_dist = world_size > 1 or comm is not None  # (a one-rank communicator still runs its collectives: see _ClipLossFn)
+        if use_dist:
             T_all = torch.empty(world_size * B, E, dtype=F32, device=dev)
             _all_gather(T_all, T, comm)
         else:
@@ -336,14 +340,14 @@ class _SigLipLossFn(torch.autograd.Function):
             dT_all = term.dY().contiguous()
         acc[1:2].sub_(b * acc[2:3]).div_(s)  # d/dscale = sum(G * (logits - bias)) / s
         ctx.save_for_backward(dI, dT_all, acc)
-        ctx.meta = (world_size, B, E, image_features.dtype, text_features.dtype, comm)
+        ctx.meta = (use_dist, B, E, image_features.dtype, text_features.dtype, comm)
         return acc[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
         dI, dT_all, acc = ctx.saved_tensors
-        world_size, B, E, idt, tdt, comm = ctx.meta
-        if world_size > 1:  # reverse of the neighbour exchange (loss.py:279-311): every chunk's grad returns to its owner
+        use_dist, B, E, idt, tdt, comm = ctx.meta
+        if use_dist:  # reverse of the neighbour exchange (loss.py:279-311): every chunk's grad returns to its owner
             dT = torch.empty(B, E, dtype=F32, device=dI.device)
             _reduce_scatter_sum(dT, dT_all, comm)
         else:

@@ -1,9 +1,11 @@
 """CPU baseline of the REFERENCE itself: ``open_clip_train.train.train_one_epoch`` (train.py:337) driving the reference's
 own ``CLIP`` + ``CLIPTask`` + AdamW on the host cores -- ViT-B-32, fp32, batch 32, world_size 1, synthetic in-memory loader (workers 0)
--- timed by an outer wall clock per step, and, in the same process and thread count, the CPU oracle (``oracle/clip_oracle.py``) that
-``bench.py``'s ``cpu_baseline`` leg times on the GPU box (where /root/reference does not exist).  TEST / BENCH INFRASTRUCTURE ONLY.
+-- timed by an outer wall clock per step AND read off the reference's own console line (train.py:456,496-502: ``samples_per_second =
+step_batch_size * world_size / batch_time``), and, in the same process and thread count, the CPU oracle (``oracle/clip_oracle.py``, the port).
+``bench.py``'s ``cpu_baseline`` leg runs this file as a subprocess on the GPU box's host cores (the reference comes out of
+``oracle/_ref/reference_src.zip`` there: oracle/fetch_ref.py, oracle/ref_shim.py).  TEST / BENCH INFRASTRUCTURE ONLY.
 
-    PYTHONDONTWRITEBYTECODE=1 python -m oracle.ref_cpu_baseline [--steps 8] [--threads N]  ->  profiles/r02_reference_cpu_train_one_epoch.json
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.ref_cpu_baseline [--steps 8] [--threads N] [--out FILE] [--no-port]
 """
 import argparse
 import json
@@ -48,9 +50,27 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_reference_cpu_train_one_epoch.json"))
+    ap.add_argument("--no-port", action="store_true", help="skip the oracle port timed in the same process")
     a = ap.parse_args()
     if a.threads:
         torch.set_num_threads(a.threads)
+    import logging
+    import re
+    from oracle.ref_shim import reference_available
+
+    class _Lines(logging.Handler):  # the reference's own console lines ("... Batch (t): 1.312, 24.3902/s, 24.3902/s/gpu ...")
+        def __init__(self):
+            super().__init__(level=logging.INFO)
+            self.rates = []
+
+        def emit(self, record):
+            m = re.search(r"Batch \(t\): [0-9.]+, ([0-9.eE+-]+)/s,", record.getMessage())
+            if m:
+                self.rates.append(float(m.group(1)))
+
+    lines = _Lines()
+    logging.getLogger().addHandler(lines)
+    logging.getLogger().setLevel(logging.INFO)
     import_reference()
     import open_clip
     from open_clip.task import CLIPTask
@@ -82,10 +102,18 @@ def main():
     steps = [stamps[i + 1] - stamps[i] for i in range(len(stamps) - 1)]
     warm = sorted(steps[2:]) if len(steps) > 3 else sorted(steps)
     med = warm[len(warm) // 2]
+    logged = sorted(lines.rates[2:]) if len(lines.rates) > 3 else sorted(lines.rates)
     rec = {"what": "reference open_clip_train.train.train_one_epoch (train.py:337), ViT-B-32 fp32, batch 32, world_size 1, CPU, synthetic in-memory batches",
-           "kind": "reference", "where": "build container (the GPU box has no /root/reference)", "nproc": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+           "kind": "reference", "where": "build container (/root/reference)" if reference_available() else "this box's host cores (reference from oracle/_ref/reference_src.zip)",
+           "nproc": os.cpu_count(), "torch_threads": torch.get_num_threads(),
            "steps": a.steps, "sec_per_step_all": [round(s, 3) for s in steps], "sec_per_step_median_warm": round(med, 3), "pairs_per_s": round(bs / med, 2),
+           "pairs_per_s_reference_log_line": (round(logged[len(logged) // 2], 2) if logged else None),  # median of the reference's own `N/s` (train.py:456)
            "torch": torch.__version__}
+    if a.no_port:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(rec, open(a.out, "w"), indent=1)
+        print(json.dumps(rec))
+        return
     # the oracle (port) in the same process / thread count: the calibration between the two CPU baselines
     from oracle import clip_oracle as O
     from open_clip_amd.synth import init_state_dict
@@ -102,7 +130,7 @@ def main():
         ts.append(time.perf_counter() - t1)
     w = sorted(ts[1:])
     rec["oracle_port_same_process"] = {"sec_per_step_median_warm": round(w[len(w) // 2], 3), "pairs_per_s": round(bs / w[len(w) // 2], 2)}
-    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(rec, open(a.out, "w"), indent=1)
     print(json.dumps(rec))
 

@@ -78,6 +78,8 @@ def test_bench_native_allreduce_paths():
     one = _bench(["--native-allreduce"])
     assert "RCCL through the C ABI" in one["config"]["gradient_allreduce"]
     assert abs(one["config"]["final_loss"] - plain["config"]["final_loss"]) < 3e-2
+    nc = _bench(["--native-comm"])  # one process, one-rank communicator: the loss's distributed (row-sharded) form with identity collectives
+    assert "ocn_comm_" in nc["config"]["loss_collectives"] and abs(nc["config"]["final_loss"] - plain["config"]["final_loss"]) < 3e-2
     acc = _bench(["--native-allreduce", "--accum-freq", "2"])
     ref = _bench(["--accum-freq", "2"])
     assert abs(acc["config"]["final_loss"] - ref["config"]["final_loss"]) < 3e-2

@@ -158,6 +158,56 @@ def test_native_comm_one_rank_collectives_through_the_c_abi():
     comm.close()
 
 
+def test_native_comm_one_rank_at_config3_payloads_and_the_loss_through_it():
+    """the argument marshalling of ocn_comm_* at BASELINE config 3's sizes (RCCL refuses more than one rank per device, so ONE rank:
+    every collective is an identity whose counts, dtypes and pointers still travel the product's path): the packed [4096, 2 x 512] fp32 feature
+    all-gather (8 MiB per rank), the [4096, 1024] reduce-scatter of the row-sharded loss, the 3-element scalar all-reduce, a 28 MB gradient-arena
+    all-reduce (mean), the parameter broadcast in fp32 / bf16 / raw bytes (int64, bool) -- and NativeClipLoss(comm=...) itself with world_size 1
+    forced through its world_size > 1 code (row-sharded: all-gather -> two [4096 x 4096] fused logits + CE -> reduce-scatter -> all-reduce) against
+    the plain world_size-1 loss.  Unmeasured on more than one GPU."""
+    from open_clip_amd import loss as L
+    from open_clip_amd.comm import NativeComm
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    comm = NativeComm(NativeComm.make_unique_id(), 0, 1)
+    g = torch.Generator(device=dev).manual_seed(21)
+    packed = torch.randn(4096, 1024, device=dev, generator=g)
+    out = torch.full_like(packed, float("nan"))
+    comm.all_gather_into_tensor(out, packed)
+    rs = torch.full_like(packed, float("nan"))
+    comm.reduce_scatter_sum(rs, packed)
+    acc = torch.randn(3, device=dev, generator=g)
+    acc0 = acc.clone()
+    comm.all_reduce_sum(acc)
+    arena = torch.randn(7_087_872, device=dev, generator=g)  # one ViT-B-32 image block's gradient arena
+    arena0 = arena.clone()
+    comm.all_reduce_avg(arena)
+    torch.cuda.synchronize()
+    assert torch.equal(out, packed) and torch.equal(rs, packed) and torch.equal(acc, acc0) and torch.equal(arena, arena0)
+    for t in (torch.randn(768, 3072, device=dev, generator=g), torch.randn(513, device=dev, generator=g).bfloat16(),
+              torch.arange(77, device=dev), torch.tensor([True, False, True], device=dev), torch.randn(5, device=dev, generator=g).half()):
+        t0 = t.clone()
+        comm.broadcast(t, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t, t0), t.dtype
+    # the loss's multi-rank branch over the communicator: with W = 1 it must reproduce the one-process loss (same kernels, same order)
+    I = torch.nn.functional.normalize(torch.randn(4096, 512, device=dev, generator=g), dim=-1)
+    T = torch.nn.functional.normalize(0.5 * I + torch.nn.functional.normalize(torch.randn(4096, 512, device=dev, generator=g), dim=-1), dim=-1)
+    res = []
+    for force in (False, True):
+        Ii, Ti, s = I.clone().requires_grad_(True), T.clone().requires_grad_(True), torch.tensor(14.28, device=dev, requires_grad=True)
+        if force:  # world_size 1 through the world_size > 1 code (a communicator is given): row-sharded, every collective through ocn_comm_*
+            loss = L.NativeClipLoss(rank=0, world_size=1, row_sharded=True, comm=comm)(Ii, Ti, s)
+        else:
+            loss = L.NativeClipLoss()(Ii, Ti, s)
+        loss.backward()
+        res.append((float(loss), Ii.grad.clone(), Ti.grad.clone(), float(s.grad)))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 and abs(res[0][3] - res[1][3]) <= 1e-5 * abs(res[0][3]) + 1e-7
+    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2])):
+        assert float((a - b).norm() / a.norm()) <= 1e-4  # identical kernels; the two forms add the row / column parts in a different order
+    comm.close()
+
+
 def _sync_twin_worker(rank, port, outdir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

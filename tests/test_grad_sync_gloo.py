@@ -102,6 +102,21 @@ def _worker(rank, world, port, q):
     for (n, p), (_, q_) in zip(c.named_parameters(), d.named_parameters()):
         if p.grad is not None:
             unused_ok = unused_ok and q_.grad is not None and bool(torch.allclose(p.grad, q_.grad, rtol=1e-5, atol=1e-7))
+    # ... and the same under ACCUMULATION: two micro-batches, the first under no_sync(), then finish() -- the bitmap is taken over
+    # the accumulated .grad, the unused parameter stays None, the rest equals DDP's (mean over ranks of the SUM over micro-batches)
+    ddp_u.zero_grad(set_to_none=True)
+    d.zero_grad(set_to_none=True)
+    with ddp_u.no_sync():
+        ddp_u(xs[1]).backward()
+    ddp_u(xs[2]).backward()
+    with sync_u.no_sync():
+        d(xs[1]).backward()
+    d(xs[2]).backward()
+    sync_u.finish()
+    unused_ok = unused_ok and d.visual.unused.grad is None and c.visual.unused.grad is None
+    for (n, p), (_, q_) in zip(c.named_parameters(), d.named_parameters()):
+        if p.grad is not None:
+            unused_ok = unused_ok and q_.grad is not None and bool(torch.allclose(p.grad, q_.grad, rtol=1e-5, atol=1e-7))
     sync_u.remove()
     e_ = _Toy(with_unused=True)
     strict = NativeGradSync(e_, world, process_group=dist.new_group())
