@@ -106,7 +106,9 @@ def load():
         #                 libamdhip64), not pull a second copy from /opt/rocm that knows no device ("no ROCm-capable device")
         lib = ctypes.CDLL(LIB_PATH)
         lib.ocn_version.argtypes, lib.ocn_version.restype = [], _i
-        if lib.ocn_version() != ABI_VERSION:
+        # OCN_ALLOW_ABI=<n> (developer, together with OCN_LIB_PATH): accept an OLDER library for a timing A/B of the step -- only entry points
+        # whose argument lists did not change since version n may then be reached (tools/gpu_call_r5.sh: the round-4 library under this tree)
+        if lib.ocn_version() != ABI_VERSION and str(lib.ocn_version()) != os.environ.get("OCN_ALLOW_ABI"):
             raise RuntimeError(f"{LIB_PATH} reports C-ABI version {lib.ocn_version()}, this package binds version {ABI_VERSION} "
                                "(include/openclip_hip.h): rebuild it with `python -m open_clip_amd.build` -- argument lists differ between versions")
         for name, argtypes in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):

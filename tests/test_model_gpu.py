@@ -672,19 +672,35 @@ def test_deterministic_step_is_bit_reproducible(cfg_name, B, siglip):
     state = init_state_dict(cfg, seed=4, perturb=True, siglip=siglip)
     batch = synthetic_batch(cfg, B, seed=12, device="cuda")
 
+    from open_clip_amd.optim import NativeAdamW, param_groups_like_reference, weight_caches_of
+    clipped = {}
+
     def run(det):
         model = _build(cfg, state, siglip=siglip, deterministic=det)
         out = model(image=batch["image"], text=batch["text"])
         loss = (NativeSigLipLoss(deterministic=det) if siglip else NativeClipLoss(deterministic=det))(**out)
         loss.backward()
         torch.cuda.synchronize()
-        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        # round 5: the clipped update too -- clip_grad_norm_'s squared-norm sum in a fixed order (NativeAdamW(deterministic=True): per-chunk partials
+        # folded by one workgroup, ocn_sumsq_multi's chunk workspace) was the one fp32-atomic sum left under deterministic=True
+        opt = NativeAdamW(param_groups_like_reference(model, 0.2), lr=1e-3, betas=(0.9, 0.98), eps=1e-6, grad_clip_norm=0.05,
+                          weight_caches=weight_caches_of(model), deterministic=det)
+        opt.step()
+        torch.cuda.synchronize()
+        clipped[len(clipped)] = (opt.last_grad_norm_sq.detach().clone(), {k: p.detach().clone() for k, p in model.named_parameters()})
+        return loss.detach().clone(), grads
 
     l1, g1 = run(True)
     l2, g2 = run(True)
     assert torch.equal(l1, l2), (float(l1), float(l2))
     diff = [k for k in g1 if not torch.equal(g1[k], g2[k])]
     assert not diff, f"{len(diff)} gradients differ between two deterministic runs: {diff[:6]}"
+    assert torch.equal(clipped[0][0], clipped[1][0]), "squared gradient norm differs between two deterministic runs"
+    pdiff = [k for k in clipped[0][1] if not torch.equal(clipped[0][1][k], clipped[1][1][k])]
+    assert not pdiff, f"{len(pdiff)} parameters differ after the clipped AdamW update of two deterministic runs: {pdiff[:6]}"
+    want = sum(float(v.double().pow(2).sum()) for v in g1.values())
+    assert abs(float(clipped[0][0]) / want - 1) <= 1e-5 and float(clipped[0][0]) ** 0.5 > 0.05  # the norm is right, and the clip was active
     l0, g0 = run(False)
     worst = max((float((g0[k] - g1[k]).norm() / (g1[k].norm() + 1e-30)), k) for k in g1)
     _report(f"deterministic step [{cfg_name}, B={B}{', siglip' if siglip else ''}]: two runs bit-identical (loss + {len(g1)} gradients); atomic form differs by "

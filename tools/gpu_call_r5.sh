@@ -1,0 +1,68 @@
+# One budgeted GPU-box call of round 5 (run through tools/gpu.sh): bash tools/gpu_call_r5.sh TAG "STEPS..."
+#   steps: tests | newtests | bench | benchquick | prof | profov | pmc | mfma | models | abstep | abnt | attn | lines
+TAG=${1:-call}; STEPS=${2:-"tests bench"}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
+QUIET="--no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-extra-lines --no-config-lines"
+OLD=$GRAFT_REPO_ROOT/tools/probes/libopenclip_hip_r04.so; DEVLIB=$GRAFT_REPO_ROOT/open_clip_amd/libopenclip_hip_dev.so
+has() { case " $STEPS " in *" $1 "*) return 0;; esac; return 1; }
+t0=$(date +%s); stamp() { echo "$1 done at +$(( $(date +%s) - t0 )) s" >> $O/${TAG}_timeline.txt; }
+nproc > $O/${TAG}_host.txt; free -g | head -2 >> $O/${TAG}_host.txt; rocm-smi --showproductname 2>/dev/null | head -12 >> $O/${TAG}_host.txt
+if has newtests; then
+  rm -f $O/parity_report.txt
+  timeout 1500 python -m pytest ${NEW_TESTS:-tests/test_parity_at_size_gpu.py tests/test_reference_dropin_gpu.py} -q --maxfail=12 --durations=12 ${NEW_TESTS_K:+-k "$NEW_TESTS_K"} 2>&1 | tail -70 > $O/${TAG}_newtests.log
+  cp $O/parity_report.txt $O/${TAG}_newtests_parity_report.txt 2>/dev/null; stamp newtests
+fi
+if has tests; then
+  rm -f $O/parity_report.txt
+  timeout 2400 python -m pytest tests -m gpu -q --maxfail=12 --durations=20 2>&1 | tail -80 > $O/${TAG}_tests.log
+  cp $O/parity_report.txt $O/${TAG}_parity_report.txt 2>/dev/null
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 > $O/${TAG}_smoke.log; stamp tests
+fi
+if has bench; then timeout 1200 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.log 2> $O/${TAG}_bench.err; stamp bench; fi
+if has benchquick; then timeout 600 python bench.py --steps 20 --warmup 5 $QUIET > $O/${TAG}_benchquick.log 2>&1; stamp benchquick; fi
+if has abstep; then  # whole step: this tree's library against the round-4 library (same Python tree), alternating processes
+  for i in 1 2; do
+    timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_abstep_new.json
+    OCN_LIB_PATH=$OLD OCN_ALLOW_ABI=101 timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_abstep_r04.json
+  done; stamp abstep
+fi
+if has abgelu; then  # c_fc + GELU GEMMs: polynomial (product) against the Abramowitz-Stegun form (developer knob), same developer library, alternating
+  for i in 1 2; do
+    OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob 0 --only +gelu --json $O/${TAG}_abgelu.jsonl >> $O/${TAG}_abgelu_poly.txt 2>&1
+    OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob 4194304 --only +gelu --json $O/${TAG}_abgelu.jsonl >> $O/${TAG}_abgelu_as.txt 2>&1
+  done; stamp abgelu
+fi
+if has models; then  # BASELINE configs 4 / 5 through the same bench on one GPU, with the roofline
+  Q2="--no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-extra-lines --no-config-lines"
+  timeout 400 python bench.py --model ViT-L-14 --local-batch 2048 --grad-checkpointing --steps 4 --warmup 1 $Q2 2>&1 | grep '^{' > $O/${TAG}_l14_bench.json
+  timeout 400 python bench.py --model ViT-H-14 --siglip --local-batch 1024 --grad-checkpointing --steps 4 --warmup 1 $Q2 2>&1 | grep '^{' > $O/${TAG}_h14_bench.json; stamp models
+fi
+if has lines; then
+  timeout 300 python bench.py --steps 8 --warmup 2 --deterministic $QUIET --no-roofline > $O/${TAG}_bench_det.log 2>&1
+  timeout 300 python bench.py --steps 8 --warmup 2 --native-comm --native-allreduce $QUIET --no-roofline > $O/${TAG}_bench_native_comm.log 2>&1; stamp lines
+fi
+if has attn; then timeout 300 python tools/ab_attn_bwd.py > $O/${TAG}_ab_attn_bwd.txt 2>&1; stamp attn; fi
+cd /tmp; export TMPDIR=/tmp
+if has prof; then  # every kernel alone on the chip (one stream, no wgrad side stream)
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $QUIET --no-roofline --serial-towers --no-wgrad-pair > $O/${TAG}_prof.log 2>&1
+  python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof -name "*.db" | head -1) > $O/${TAG}_kernel_stats.txt 2>&1; stamp prof
+fi
+if has profov; then  # the step AS SHIPPED (towers overlapped: a kernel's duration includes what it shares the chip with)
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $QUIET --no-roofline > $O/${TAG}_prof_overlap.log 2>&1
+  python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof2 -name "*.db" | head -1) > $O/${TAG}_kernel_stats_overlap.txt 2>&1; stamp profov
+fi
+pmc_pass() {  # $1 = file tag, $2 = counters
+  timeout 400 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d /tmp/pmc_$1 -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 $QUIET --no-roofline --serial-towers --no-wgrad-pair > $O/${TAG}_pmc_$1.log 2>&1
+  find /tmp/pmc_$1 -name "*counter_collection.csv" -exec cp {} $O/${TAG}_pmc_$1.csv \;
+}
+if has pmc; then
+  pmc_pass FETCH_SIZE FETCH_SIZE; pmc_pass WRITE_SIZE WRITE_SIZE
+  python $GRAFT_REPO_ROOT/tools/pmc_stats.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json $(cat $GRAFT_REPO_ROOT/.head_sha 2>/dev/null) > $O/${TAG}_pmc_hbm_traffic.txt 2>&1
+  rm -f $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv; stamp pmc
+fi
+if has mfma; then
+  pmc_pass SQ_VALU_MFMA_BUSY_CYCLES "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES"
+  python $GRAFT_REPO_ROOT/tools/pmc_mfma.py $O/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv > $O/${TAG}_pmc_mfma_util.txt 2>&1
+  rm -f $O/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv; stamp mfma
+fi
+echo "end +$(( $(date +%s) - t0 )) s" >> $O/${TAG}_timeline.txt
