@@ -213,7 +213,7 @@ def _reference_cpu_live(threads, steps=8, timeout=240):
         return {"error": repr(e)[:300]}
 
 
-def cpu_baseline(model_name, seconds=12.0):
+def cpu_baseline(model_name, seconds=30.0):
     """The CPU baseline beside the native step, on this box's host cores, at the reference's CPU configuration (ViT-B-32 fp32, batch 32):
     ``kind: "reference"`` -- the reference's own train_one_epoch (``_reference_cpu_live``), its pairs/s from the outer wall clock and from the
     reference's own log line -- whenever the reference's packages are here; the CPU oracle (port of the reference path, fwd+bwd+AdamW) is timed
@@ -242,12 +242,12 @@ def cpu_baseline(model_name, seconds=12.0):
     t_start = time.time()
     one()  # first touch (allocator, thread pool)
     sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu}):  # (batch 32 stops scaling at 8-32 threads on every host seen so far)
         torch.set_num_threads(th)
         one()
         sweep[th] = round(one(), 3)
-        if time.time() - t_start > seconds:
-            break
+        if time.time() - t_start > seconds or (len(sweep) >= 2 and sweep[th] > 1.15 * min(sweep.values())):
+            break  # out of budget, or past the best setting
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     times = [one() for _ in range(3)]

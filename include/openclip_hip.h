@@ -44,7 +44,7 @@ enum ocn_epilogue {
 const char* ocn_last_error(void);
 /* ABI version of this header: ocn_version() of the library that is loaded must EQUAL it (open_clip_amd/_lib.py::load and
  * __graft_entry__.build() check; a stale .so behind OCN_LIB_PATH would otherwise receive shifted arguments without any error).
- *   102 (round 5)  ocn_sumsq_multi takes a per-chunk workspace (reproducible sum).  BREAKING since 101 and now carried by the number:
+ *   102 (round 5)  ocn_sumsq_multi takes a per-chunk workspace (reproducible sum); ocn_siglip_rows takes the bias as a device value.  BREAKING since 101 and now carried by the number:
  *                  ocn_layernorm_bwd / ocn_embed_assemble_bwd / ocn_token_embed_bwd_sorted[_varlen] / ocn_softmax_ce_rows / ocn_siglip_rows took
  *                  extra arguments in round 4, and the logit-gradient matrix G written by ocn_softmax_ce_rows / ocn_fused_logits_ce /
  *                  ocn_siglip_rows holds softmax (sigmoid) * grad_scale WITHOUT the -onehot term (the caller applies it as an exact rank-1
@@ -256,8 +256,10 @@ int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, in
 int64_t ocn_fused_logits_ce_workspace_floats(int R, int N);
 int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
                         float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
+/* bias_dev (may be NULL): the logit bias as a 1-element DEVICE value; overrides `bias` (logit_bias is a parameter: the step never reads it on the
+ * host).  It is subtracted per element inside the dscale sum -- not as bias * dbias_sum afterwards, which cancels catastrophically. */
 int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,
-                    float bias, float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
+                    float bias, const float* bias_dev, float loss_scale, float grad_scale, float inv_logit_scale, float* loss_sum,
                     float* dscale_sum, float* dbias_sum, float* det_rows, ocn_stream_t stream);
 
 /* ---- optimizer (train.py:181-182, image_text_task.py:91-101) --------------

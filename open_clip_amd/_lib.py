@@ -55,7 +55,7 @@ SIGNATURES = {
     "ocn_l2norm_bwd": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_softmax_ce_rows": [_p, _i, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p],
     "ocn_fused_logits_ce": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p, _p, _p, _p],
-    "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p],
+    "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _f, _f, _f, _p, _p, _p, _p, _p],
     "ocn_sumsq_accum": [_p, _l, _p, _p],
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
     "ocn_adamw_multi": [_p, _p, _i, _f, _f, _f, _p, _f, _p],

@@ -117,18 +117,22 @@ class _PairTerm:
         ops.softmax_ce_rows(self._materialise(), self.G, self.N, label_offset, loss_scale, grad_scale, 1.0, acc[0:1], acc[1:2])
 
     def siglip(self, label_offset, negative_only, loss_scale, grad_scale, acc):
-        """acc[0] += loss, acc[1] += sum(G * logits) (bias included: the caller subtracts bias * acc[2]), acc[2] += sum(G)"""
+        """acc[0] += loss, acc[1] += sum(g * (logits - bias)) (= s * d/dscale; the bias is read on the device and subtracted per element),
+        acc[2] += sum(g) (= d/dbias)"""
         self._onehot = None if negative_only else (int(label_offset), float(grad_scale))  # G = sigmoid * grad_scale; the positives' -1 in dX / dY
         if self.deterministic:
             rows = torch.empty(self.R, 3, dtype=F32, device=self.X.device)
-            ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
+            ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, self._bias_dev(), loss_scale, grad_scale, 1.0,
                             acc[0:1], acc[1:2], acc[2:3], det_rows=rows)
             tot = torch.zeros(3, dtype=F32, device=self.X.device)
             ops.colsum_f32(rows, tot, deterministic=True)
             acc[0:3].add_(tot)
             return
-        ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, 0.0, loss_scale, grad_scale, 1.0,
+        ops.siglip_rows(self._materialise(), self.G, self.N, label_offset, negative_only, self._bias_dev(), loss_scale, grad_scale, 1.0,
                         acc[0:1], acc[1:2], acc[2:3])
+
+    def _bias_dev(self):
+        return 0.0 if self._bias is None else self._bias.detach().reshape(1).to(F32).contiguous()
 
     def dX(self):
         """s * G @ Y  -> [R, E] fp32"""
@@ -338,7 +342,7 @@ class _SigLipLossFn(torch.autograd.Function):
             term.siglip(B * rank, 0, 1.0 / B, 1.0 / B, acc)
             dI = term.dX()
             dT_all = term.dY().contiguous()
-        acc[1:2].sub_(b * acc[2:3]).div_(s)  # d/dscale = sum(G * (logits - bias)) / s
+        acc[1:2].div_(s)  # d/dscale = sum(g * (logits - bias)) / s (the bias is subtracted per element inside the kernel)
         ctx.save_for_backward(dI, dT_all, acc)
         ctx.meta = (use_dist, B, E, image_features.dtype, text_features.dtype, comm)
         return acc[0].clone()

@@ -459,9 +459,11 @@ def fused_logits_ce_supported(R, N, E):
 
 
 def siglip_rows(logits, G, N, label_offset, negative_only, bias, loss_scale, grad_scale, inv_logit_scale, loss_sum, dscale_sum, dbias_sum, det_rows=None):
+    """``bias``: the bias the logits carry -- a python float, or a 1-element fp32 DEVICE tensor (no host read); dscale_sum += sum(g * (logits - bias))"""
     pl, ld = _chk2d(logits, F32, "logits")
     pg, ldg = _chk2d(G, BF16, "G")
-    _lib.call("ocn_siglip_rows", pl, ld, pg, ldg, logits.shape[0], N, int(label_offset), int(negative_only), float(bias),
+    bias_dev = _chk(bias, F32, "bias") if torch.is_tensor(bias) else 0
+    _lib.call("ocn_siglip_rows", pl, ld, pg, ldg, logits.shape[0], N, int(label_offset), int(negative_only), 0.0 if bias_dev else float(bias), bias_dev,
               float(loss_scale), float(grad_scale), float(inv_logit_scale), _chk(loss_sum, F32, "loss_sum"),
               _chk(dscale_sum, F32, "dscale_sum"), _chk(dbias_sum, F32, "dbias_sum"), _chk(det_rows, F32, "det_rows"), _stream())
 

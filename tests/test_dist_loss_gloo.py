@@ -23,7 +23,8 @@ class CpuPairTerm:
         self.R, self.N, self.E = X.shape[0], Y.shape[0], X.shape[1]
 
     def compute_logits(self, bias=None):
-        self.logits = (self.s * self.X) @ self.Y.t() + (0.0 if bias is None else bias.detach())
+        self.bias = 0.0 if bias is None else bias.detach()
+        self.logits = (self.s * self.X) @ self.Y.t() + self.bias
         return self
 
     def softmax_ce(self, label_offset, loss_scale, grad_scale, acc):
@@ -43,7 +44,7 @@ class CpuPairTerm:
         z = lab * self.logits
         acc[0] += (-torch.nn.functional.logsigmoid(z)).sum() * loss_scale
         self.G = -lab * torch.sigmoid(-z) * grad_scale
-        acc[1] += (self.G * self.logits).sum()
+        acc[1] += (self.G * (self.logits - self.bias)).sum()  # the bias subtracted per element, as ocn_siglip_rows does
         acc[2] += self.G.sum()
 
     def dX(self):

@@ -57,7 +57,7 @@ def test_reference_train_one_epoch_trains_the_native_model_on_the_gpu():
 
     class Lines(logging.Handler):
         def emit(self, record):
-            m = re.search(r"Contrastive_loss: ([0-9.]+)", record.getMessage())
+            m = re.search(r"^Train Epoch: .* Contrastive_loss: ([0-9.]+)", record.getMessage())  # (not the "End epoch ... Avg Contrastive_loss" summary)
             if m:
                 losses.append(float(m.group(1)))
 
