@@ -55,6 +55,19 @@ def main():
                 print(f"{k:7d} {t / 1e6:10.3f} {t / k / 1e3:10.2f}  {str(g):>22s} {str(w):>14s}  {n[:60]}  [{workgroups} workgroups]")
     else:
         print("# (this rocpd build exposes no grid / workgroup columns in `kernels`: per-geometry rows not available; columns: " + ", ".join(cols) + ")")
+    # steady state: the same table over the SECOND HALF of the dispatches only (the first step of a run also initialises the optimizer's moments,
+    # the bf16 operand copies, ...: 604 of the 784 zero-fills of a 4-step trace belong to it)
+    half_raw = raw[len(raw) // 2:]
+    agg2 = {}
+    for r in half_raw:
+        a = agg2.setdefault(short(r[0]), [0, 0])
+        a[0] += 1
+        a[1] += r[2] - r[1]
+    tot2 = sum(a[1] for a in agg2.values())
+    print(f"# second half of the dispatches only ({len(half_raw)} dispatches, kernel time {tot2 / 1e6:.2f} ms): elementwise / fill / copy kernels of the framework")
+    for n, (k, t) in sorted(agg2.items(), key=lambda kv: -kv[1][1]):
+        if "at::native" in n or "rocclr" in n:
+            print(f"{k:7d} {t / 1e6:10.3f} {t / k / 1e3:10.2f} {100.0 * t / tot2:6.2f}  {n}")
     # how many kernels share the chip, over the busiest contiguous stretch (the timed steps: from the first dispatch of the second half
     # of the trace to the last one): time with 0 / 1 / 2 / 3+ kernels in flight
     half = rows[len(rows) // 2:]
