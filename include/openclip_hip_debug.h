@@ -21,13 +21,14 @@ extern "C" {
  *              epilogue's stores / operand loads (results wrong), & 64 timeline build, & 0x200000 whole tail tiles instead of half tiles,
  *              & 0x400000 GELU arithmetic by the Abramowitz-Stegun erfc form that shipped until round 4 (gelu_both_as; the product uses the polynomial
  *                         normal CDF gelu_both_poly4; same tolerances, tests/test_dev_build_gpu.py);
- *              (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us (63 = off).
+ *              (v >> 16) & 31 tile-walk band width; (v >> 21) & 63 start stagger in us per class (0 / 63 = off = shipped since round 5; 62 = the automatic rule that shipped until round 4).
  *              The knobs of this group that live INSIDE the kernel exist in the developer build only (libopenclip_hip_dev.so:
  *              python -m open_clip_amd.build --dev, -DOCN_DEV_BUILD; select it with OCN_LIB_PATH): the product library compiles none of
  *              them and ignores these bits. */
 int ocn_set_gemm_variant(int nt_variant);
 /* developer knobs (process-global; experiments and A/B measurements of tools/sweep.py, never needed by a user):
  *   key 1  attention-backward ablation mask (1 skip the input staging, 2 skip the arithmetic, 4 skip the stores: results wrong)
+ *   key 3  persistent NT GEMM (developer build): which workgroups share a start-stagger class: 0 consecutive workgroups alternate (shipped), 1 per XCD, 2 per tile row of the band
  *   key 2  attention backward: 4 = two-pass dK / dV build, 5 = one-pass build (default: two-pass up to 4 waves)   key 4  wgrad GEMM: 1 = skip the atomic epilogue
  *   key 5  attention backward: extra KiB of LDS per workgroup (occupancy probe)  key 6  1 = generic instead of causal bwd kernel
  *   key 7  1 = always the streamed (explicit head_dim) attention kernels, 2 = always the head-resident ones (head_dim 64, L <= 320)

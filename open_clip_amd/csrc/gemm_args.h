@@ -14,6 +14,7 @@ struct GemmNtArgs {
     int tiles_n, ntiles;
     int stagger; // start offset between the 4 phase classes of workgroups, in 100 MHz ticks (0 = none; gemm_nt5.hip)
     int first_wave;  // workgroups [0, first_wave) start together (one per CU) and are the ones that get staggered
+    int stagger_mode;  // which workgroups share a phase class (gemm_nt5.hip; 0 = shipped; other values: developer build only, ocn_set_tuning key 3)
     int band;    // tile walk order: column bands of `band` n-tiles, row-major inside a band (gemm_nt5.hip)
     // the launch's last, partial round of tiles computed as HALF tiles (gemm_nt5.hip; set by launch5, 0 = off): tiles [tail_first, tail_first +
     // tail_n) of the walk are split; workgroup j < tail_n takes the upper half of tail tile j, workgroup tail_partner + j the lower half

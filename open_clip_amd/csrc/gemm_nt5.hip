@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
 #define DMA_B0(J, P) DMA(dB, voB, ab_k, B_SLOT(0, P), J)
 #define DMA_B1(J, P) DMA(dB, voB, ab_k + b_half, B_SLOT(1, P), J)
 
-    // ---- phase stagger -------------------------------------------------------------------------------------------
+    // ---- phase stagger (a.stagger > 0: developer build only since round 5 -- see nt5_stagger: it stopped paying) ---------------
     // Persistent workgroups launched together walk tiles of equal cost in lockstep: every CU is in its main loop (HBM
     // idle) and then every CU is in its epilogue at once -- a chip-wide burst of 256 x 128..256 KiB of stores (+ residual /
     // pre-activation reads) that exceeds what the L2s can buffer, so the epilogue runs at HBM write speed while the MFMA
@@ -538,7 +538,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // bf16 output; profiles/r01_nt5_tile_timeline.txt).  Workgroups therefore start in 4 phase classes (inside every XCD),
     // a quarter of a tile time apart, which spreads the epilogue traffic over the whole tile period.
     if (a.stagger > 0 && (int)blockIdx.x < a.first_wave) {  // later workgroups start whenever a CU frees up: already spread out
-        const int phase = ((int)blockIdx.x >> 3) & 3;
+        int phase = ((int)blockIdx.x >> 3) & 3;
+#ifdef OCN_DEV_BUILD
+        // developer knob (ocn_set_tuning key 3): WHICH workgroups share a phase class.  0 (shipped): consecutive workgroups of an XCD take classes
+        // 0,1,2,3,0,.. -- the `band` workgroups that stream the same A panel sit in four different classes, up to 3/4 of a tile apart in k;
+        // 1: every workgroup of an XCD in one class (XCD = blockIdx % 8: the panel sharers run in step, the bursts of two XCDs coincide);
+        // 2: the workgroups of one tile ROW of the band in one class (A-panel sharers in step, rows spread over the four classes)
+        if (a.stagger_mode == 1) phase = (int)blockIdx.x & 3;
+        else if (a.stagger_mode == 2) {
+            int m0s, n0s;
+            tile_origin(0, m0s, n0s);
+            phase = (m0s >> 8) & 3;
+        }
+#endif
         if (phase) {
             const long long until = wall_clock64() + (long long)phase * a.stagger;
             while (wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
@@ -833,13 +845,16 @@ int nt5_band(int M, int N, int K, int forced) {
     return tiles_n;
 }
 
-// Phase offset between workgroup classes (100 MHz ticks): a quarter of the expected tile time (main loop ~2 us per 64-wide
-// K-tile + epilogue), only for epilogues whose burst does not fit the L2s and only when a workgroup walks enough tiles to
-// repay the one-off delay.  `forced` (developer knob, us per phase): 0 = automatic, 63 = off.
+// Start stagger between four classes of workgroups (100 MHz ticks per class; see the kernel).  It was worth +5 % on the c_fc + GELU GEMM when the
+// epilogues waited for their own operands and stored 4 bytes per element of the second output (round 1); with the operands fetched ahead by the
+// main loop and the 8-bit second output it COSTS 1.4 % on the four GELU / dGELU shapes and 0.4 ms on the step (round 5, profiles/
+// r05_nt5_start_stagger.txt: every run of three alternations), and no assignment of workgroups to classes (per XCD, per tile row) does better
+// than none.  Off in the product; `forced` (developer build, us per class) brings it back for measurements: 0 = off, 63 = off, 62 = the old
+// automatic rule (a quarter of the expected tile time for the heavy epilogues when a workgroup walks >= 12 tiles).
 template <int EPI>
 int nt5_stagger(int ntiles, int K, int forced) {
-    if (forced == 63) return 0;
-    if (forced > 0) return forced * 100;
+    if (forced == 0 || forced == 63) return 0;
+    if (forced != 62) return forced * 100;
     constexpr bool heavy = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU || EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     if (!heavy || ntiles < 12 * g_num_cu) return 0;
     const int tile_us = (K / 64) * 2 + 6;
@@ -874,6 +889,11 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
     a.stagger = nt5_stagger<EPI>(a.ntiles, a.K, (a.ablate >> 13) & 63);
     a.first_wave = g_num_cu;
+#ifdef OCN_DEV_BUILD
+    a.stagger_mode = g_ocn_tuning[3];
+#else
+    a.stagger_mode = 0;
+#endif
     // One workgroup per CU.  Developer knob 10 = k launches k per CU with 1/k of the tiles each (they queue behind each other on a
     // CU): a workgroup that cannot start with the rest -- a CU held by another stream's kernel, e.g. a collective -- then delays the
     // launch by 1/k of its length instead of by half of it (one CU held: +50 % at k = 1, +11..18 % at k = 3;

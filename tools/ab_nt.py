@@ -16,6 +16,7 @@ ap.add_argument("--knob", type=int, default=0)
 ap.add_argument("--only", default="")
 ap.add_argument("--json", default="")
 ap.add_argument("--iters", type=int, default=8)
+ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE", help="ocn_set_tuning(KEY, VALUE) before the run (developer knobs)")
 args = ap.parse_args()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open_clip_amd import _lib  # noqa: E402
@@ -49,8 +50,11 @@ def timeit(fn, iters):
 
 if args.knob:
     _lib.call("ocn_set_gemm_variant", args.knob << 8)
+for kv in args.tuning:
+    k, v = kv.split("=")
+    _lib.call("ocn_set_tuning", int(k), int(v))
 st = torch.cuda.current_stream().cuda_stream
-print(f"# library: {_lib.LIB_PATH}  knob {args.knob}")
+print(f"# library: {_lib.LIB_PATH}  knob {args.knob}  tuning {args.tuning}")
 res = {}
 tot = 0.0
 for name, epi, M, N, K in SHAPES:
@@ -72,4 +76,4 @@ for name, epi, M, N, K in SHAPES:
 print(f"# sum {tot:.3f} ms")
 if args.json:
     with open(args.json, "a") as f:
-        f.write(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "knob": args.knob, "ms": res, "sum": tot}) + "\n")
+        f.write(json.dumps({"lib": os.path.basename(_lib.LIB_PATH), "knob": args.knob, "tuning": args.tuning, "ms": res, "sum": tot}) + "\n")

@@ -41,6 +41,24 @@ if has lines; then
   timeout 300 python bench.py --steps 8 --warmup 2 --deterministic $QUIET --no-roofline > $O/${TAG}_bench_det.log 2>&1
   timeout 300 python bench.py --steps 8 --warmup 2 --native-comm --native-allreduce $QUIET --no-roofline > $O/${TAG}_bench_native_comm.log 2>&1; stamp lines
 fi
+if has stagger; then  # start-stagger classes of the persistent NT GEMM (developer build, ocn_set_tuning key 3) on the four GELU / dGELU shapes, alternating
+  for i in 1 2; do
+    for m in 0 1 2; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --tuning 3=$m --only gelu --json $O/${TAG}_stagger.jsonl >> $O/${TAG}_stagger_mode$m.txt 2>&1; done
+    OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $((63 << 13)) --only gelu --json $O/${TAG}_stagger.jsonl >> $O/${TAG}_stagger_off.txt 2>&1
+  done; stamp stagger
+fi
+if has abstagger; then  # whole step, developer library: start stagger as shipped vs off (knob 63 << 13 of the ablation mask = gemm variant 63 << 21), alternating
+  for i in 1 2 3; do
+    OCN_LIB_PATH=$DEVLIB timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET 2>&1 | grep '^{' >> $O/${TAG}_abstagger_on.json
+    OCN_LIB_PATH=$DEVLIB timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --gemm-variant $((63 << 21)) 2>&1 | grep '^{' >> $O/${TAG}_abstagger_off.json
+  done; stamp abstagger
+fi
+if has shapes; then timeout 300 python tools/ab_nt.py --json $O/${TAG}_shapes.jsonl > $O/${TAG}_shapes.txt 2>&1; timeout 300 python tools/gemm_vendor_yardstick.py > $O/${TAG}_gemm_vs_vendor.txt 2>&1; stamp shapes; fi
+if has band; then  # tile-walk band width (knob bits 8..12 of the ablation mask) on the four GELU / dGELU shapes
+  for i in 1 2; do
+    for b in 3 4 12; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $((b << 8)) --only gelu --json $O/${TAG}_band.jsonl >> $O/${TAG}_band$b.txt 2>&1; done
+  done; stamp band
+fi
 if has attn; then timeout 300 python tools/ab_attn_bwd.py > $O/${TAG}_ab_attn_bwd.txt 2>&1; stamp attn; fi
 cd /tmp; export TMPDIR=/tmp
 if has prof; then  # every kernel alone on the chip (one stream, no wgrad side stream)
