@@ -54,6 +54,11 @@ if has abstagger; then  # whole step, developer library: start stagger as shippe
   done; stamp abstagger
 fi
 if has shapes; then timeout 300 python tools/ab_nt.py --json $O/${TAG}_shapes.jsonl > $O/${TAG}_shapes.txt 2>&1; timeout 300 python tools/gemm_vendor_yardstick.py > $O/${TAG}_gemm_vs_vendor.txt 2>&1; stamp shapes; fi
+if has geluform; then  # polynomial vs Abramowitz-Stegun GELU arithmetic under the whole-step parity tests at size (developer library)
+  rm -f $O/parity_report.txt
+  for f in poly as; do for c in h14 b32; do OCN_LIB_PATH=$DEVLIB timeout 400 python tools/parity_gelu_form_probe.py $f $c >> $O/${TAG}_geluform.log 2>&1; done; done
+  cp $O/parity_report.txt $O/${TAG}_geluform_parity_report.txt; stamp geluform
+fi
 if has band; then  # tile-walk band width (knob bits 8..12 of the ablation mask) on the four GELU / dGELU shapes
   for i in 1 2; do
     for b in 3 4 12; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $((b << 8)) --only gelu --json $O/${TAG}_band.jsonl >> $O/${TAG}_band$b.txt 2>&1; done
