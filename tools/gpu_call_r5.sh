@@ -39,7 +39,9 @@ if has models; then  # BASELINE configs 4 / 5 through the same bench on one GPU,
 fi
 if has lines; then
   timeout 300 python bench.py --steps 8 --warmup 2 --deterministic $QUIET --no-roofline > $O/${TAG}_bench_det.log 2>&1
-  timeout 300 python bench.py --steps 8 --warmup 2 --native-comm --native-allreduce $QUIET --no-roofline > $O/${TAG}_bench_native_comm.log 2>&1; stamp lines
+  timeout 300 python bench.py --steps 8 --warmup 2 --native-comm --native-allreduce $QUIET --no-roofline > $O/${TAG}_bench_native_comm.log 2>&1
+  timeout 300 python bench.py --steps 8 --warmup 2 --h2d $QUIET --no-roofline > $O/${TAG}_bench_h2d.log 2>&1
+  timeout 300 python bench.py --steps 8 --warmup 2 --force-ddp $QUIET --no-roofline > $O/${TAG}_bench_ddp1.log 2>&1; stamp lines
 fi
 if has stagger; then  # start-stagger classes of the persistent NT GEMM (developer build, ocn_set_tuning key 3) on the four GELU / dGELU shapes, alternating
   for i in 1 2; do
@@ -66,6 +68,13 @@ if has band; then  # tile-walk band width (knob bits 8..12 of the ablation mask)
 fi
 if has attn; then timeout 300 python tools/ab_attn_bwd.py > $O/${TAG}_ab_attn_bwd.txt 2>&1; stamp attn; fi
 cd /tmp; export TMPDIR=/tmp
+if has profmodels; then  # BASELINE configs 4 / 5: kernel traces of the same bench lines (as shipped: towers overlapped)
+  Q2="--no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-extra-lines --no-config-lines --no-roofline --serial-towers --no-wgrad-pair"
+  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_l14 -o t -- python $GRAFT_REPO_ROOT/bench.py --model ViT-L-14 --local-batch 2048 --grad-checkpointing --steps 2 --warmup 1 $Q2 > $O/${TAG}_l14_prof.log 2>&1
+  python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof_l14 -name "*.db" | head -1) > $O/${TAG}_l14_kernel_stats.txt 2>&1
+  timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/prof_h14 -o t -- python $GRAFT_REPO_ROOT/bench.py --model ViT-H-14 --siglip --local-batch 1024 --grad-checkpointing --steps 2 --warmup 1 $Q2 > $O/${TAG}_h14_prof.log 2>&1
+  python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof_h14 -name "*.db" | head -1) > $O/${TAG}_h14_kernel_stats.txt 2>&1; stamp profmodels
+fi
 if has prof; then  # every kernel alone on the chip (one stream, no wgrad side stream)
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $QUIET --no-roofline --serial-towers --no-wgrad-pair > $O/${TAG}_prof.log 2>&1
   python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof -name "*.db" | head -1) > $O/${TAG}_kernel_stats.txt 2>&1; stamp prof
