@@ -1,5 +1,5 @@
 # One budgeted GPU-box call of round 5 (run through tools/gpu.sh): bash tools/gpu_call_r5.sh TAG "STEPS..."
-#   steps: tests | newtests | bench | benchquick | prof | profov | pmc | mfma | models | abstep | abnt | attn | lines
+#   steps: tests | newtests | bench | benchquick | abstep | abgelu | abstagger | stagger | band | shapes | geluform | tnepi | models | lines | attn | profmodels | prof | profov | pmc | mfma
 TAG=${1:-call}; STEPS=${2:-"tests bench"}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
 QUIET="--no-cpu-baseline --no-eager-baseline --no-dense-text-line --no-extra-lines --no-config-lines"
