@@ -62,6 +62,7 @@ if has geluform; then  # polynomial vs Abramowitz-Stegun GELU arithmetic under t
   cp $O/parity_report.txt $O/${TAG}_geluform_parity_report.txt; stamp geluform
 fi
 if has tnepi; then timeout 300 python tools/ab_tn_epilogue.py > $O/${TAG}_tn_epilogue.txt 2>&1; stamp tnepi; fi
+if has accumloss; then timeout 300 python tools/accum_loss_cost.py > $O/${TAG}_accum_loss_cost.txt 2>&1; stamp accumloss; fi
 if has band; then  # tile-walk band width (knob bits 8..12 of the ablation mask) on the four GELU / dGELU shapes
   for i in 1 2; do
     for b in 3 4 12; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $((b << 8)) --only gelu --json $O/${TAG}_band.jsonl >> $O/${TAG}_band$b.txt 2>&1; done
