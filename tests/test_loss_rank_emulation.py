@@ -38,6 +38,17 @@ def test_row_sharded_and_global_cliploss_emulation(monkeypatch):
     cols = torch.stack(coll.rs_inputs).sum(0)
     assert torch.allclose(torch.cat(dI) + cols[:, :E], dI_ref, atol=1e-6) and torch.allclose(torch.cat(dT) + cols[:, E:], dT_ref, atol=1e-6)
     assert abs(float(torch.stack(losses).sum()) - float(loss_ref)) < 1e-5 and abs(float(torch.stack(ds).sum()) - float(ds_ref)) < 1e-6
+    # local_loss + gather_with_grad on every rank: the ranks' losses sum to W x the global loss, local + reduce-scattered gradients to W x its gradient
+    coll.rs_inputs.clear()
+    dI, dT, ds, losses = [], [], [], []
+    for r in range(W):
+        Ir, Tr, sr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True), s.clone().requires_grad_(True)
+        loss = L.NativeClipLoss(local_loss=True, gather_with_grad=True, rank=r, world_size=W)(Ir, Tr, sr)
+        loss.backward()
+        dI.append(Ir.grad), dT.append(Tr.grad), ds.append(sr.grad), losses.append(loss.detach())
+    cols = torch.stack(coll.rs_inputs).sum(0)
+    assert torch.allclose(torch.cat(dI) + cols[:, :E], W * dI_ref, atol=1e-5) and torch.allclose(torch.cat(dT) + cols[:, E:], W * dT_ref, atol=1e-5)
+    assert abs(float(torch.stack(losses).sum()) - W * float(loss_ref)) < 1e-4 and abs(float(torch.stack(ds).sum()) - W * float(ds_ref)) < 1e-5
     r = 2
     Ir, Tr, sr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True), s.clone().requires_grad_(True)
     loss = L.NativeClipLoss(rank=r, world_size=W, row_sharded=False)(Ir, Tr, sr)

@@ -177,7 +177,7 @@ from tests.rank_emulation import Collectives as _Collectives, unit_features as _
 
 
 def test_cliploss_distributed_branches_at_config3_size(monkeypatch):
-    """BASELINE config 3: world 8 x local 4096, E = 512 -> N = 32768.  (a) the row-sharded global loss (bench.py's default for N > 1): EVERY rank's
+    """BASELINE config 3: world 8 x local 4096, E = 512 -> N = 32768.  (a') further down: local_loss + gather_with_grad on every rank.  (a) the row-sharded global loss (bench.py's default for N > 1): EVERY rank's
     launch -- [4096 x 32768] logits both ways with label_offset = 4096 * rank -- with the reduce-scatter of the column gradients and the scalar
     all-reduce formed from the ranks' own contributions; (b) the reference's redundant global form on one rank (two [32768 x 32768] fused
     logits + cross-entropy launches, the local slice of the result).  Against fp32 torch on the gathered features: loss, d image_features,
@@ -223,6 +223,26 @@ def test_cliploss_distributed_branches_at_config3_size(monkeypatch):
     cm = max(_rel(dI.sum(0), ref["dI"].sum(0)), _rel(dT.sum(0), ref["dT"].sum(0)))
     _report(f"ClipLoss row-sharded @ W8 x 4096 x E512: |sum_b error| / |sum_b gradient| = {cm:.3e}")
     assert cm <= 5e-2  # (the round-4 defect stood at 0.235 here; measured after the fix: 7e-4 / 4e-3 on the bench's own features)
+    # (a') local_loss + gather_with_grad -- the mode used at scale (README.md:255-260; loss.py:103-104, :82-83, :23-26): rank r's loss is the mean over ITS rows of
+    # both directions (labels offset by 4096 r), the gathered operands carry gradient and the backward of the all-gather is a reduce-scatter (sum).  Summed over
+    # the ranks the losses are W x the global loss, so local gradient + reduce-scattered contributions must equal W x the reference's gradient of the global loss
+    coll.rs_inputs.clear()
+    dI_loc, dT_loc, dscale, losses = [], [], [], []
+    for r in range(W):
+        Ir, Tr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True)
+        sr = s.clone().requires_grad_(True)
+        loss = L.NativeClipLoss(local_loss=True, gather_with_grad=True, rank=r, world_size=W)(Ir, Tr, sr)
+        loss.backward()
+        dI_loc.append(Ir.grad), dT_loc.append(Tr.grad), dscale.append(sr.grad), losses.append(loss.detach())
+    assert len(coll.rs_inputs) == W  # one reduce-scatter per rank, in its backward
+    through = torch.stack(coll.rs_inputs).sum(0)  # [N, 2E]: d I_all | d T_all summed over the ranks = what the reduce-scatter hands back, slice by slice
+    dI, dT = torch.cat(dI_loc) + through[:, :E], torch.cat(dT_loc) + through[:, E:]
+    lI, lT = _rel(dI, W * ref["dI"]), _rel(dT, W * ref["dT"])
+    lsum, dsum = float(torch.stack(losses).sum()), float(torch.stack(dscale).sum())
+    _report(f"ClipLoss local_loss + gather_with_grad @ W8 x 4096 x E512: sum of the ranks' losses {lsum:.6f} vs W x global {W * float(ref['loss']):.6f}; dI rel_l2 {lI:.3e} dT {lT:.3e} "
+            f"(against W x the global gradient); sum of dscale {dsum:.6e} vs {W * float(ref['dscale']):.6e}")
+    assert abs(lsum - W * float(ref["loss"])) <= 2e-2 and lI <= 1e-2 and lT <= 1e-2
+    assert abs(dsum - W * float(ref["dscale"])) <= 2e-2 * abs(W * float(ref["dscale"])) + 1e-6
     # (b) the reference's redundant global form, rank 5: local slices of the full-batch gradient
     r = 5
     Ir, Tr, sr = I[r * B:(r + 1) * B].clone().requires_grad_(True), T[r * B:(r + 1) * B].clone().requires_grad_(True), s.clone().requires_grad_(True)

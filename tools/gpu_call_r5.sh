@@ -63,6 +63,12 @@ if has geluform; then  # polynomial vs Abramowitz-Stegun GELU arithmetic under t
 fi
 if has tnepi; then timeout 300 python tools/ab_tn_epilogue.py > $O/${TAG}_tn_epilogue.txt 2>&1; stamp tnepi; fi
 if has accumloss; then timeout 300 python tools/accum_loss_cost.py > $O/${TAG}_accum_loss_cost.txt 2>&1; stamp accumloss; fi
+if has abclock; then  # does the rocm-smi sampler thread cost step time?  alternating
+  for i in 1 2 3; do
+    timeout 300 python bench.py --steps 20 --warmup 5 $QUIET --no-roofline 2>&1 | grep '^{' >> $O/${TAG}_abclock_on.json
+    timeout 300 python bench.py --steps 20 --warmup 5 $QUIET --no-roofline --no-clock-sample 2>&1 | grep '^{' >> $O/${TAG}_abclock_off.json
+  done; stamp abclock
+fi
 if has band; then  # tile-walk band width (knob bits 8..12 of the ablation mask) on the four GELU / dGELU shapes
   for i in 1 2; do
     for b in 3 4 12; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $((b << 8)) --only gelu --json $O/${TAG}_band.jsonl >> $O/${TAG}_band$b.txt 2>&1; done
