@@ -69,6 +69,7 @@ if has abclock; then  # does the rocm-smi sampler thread cost step time?  altern
     timeout 300 python bench.py --steps 20 --warmup 5 $QUIET --no-roofline --no-clock-sample 2>&1 | grep '^{' >> $O/${TAG}_abclock_off.json
   done; stamp abclock
 fi
+if has attnocc; then OCN_LIB_PATH=$DEVLIB timeout 300 python tools/attn_bwd_occupancy_probe.py > $O/${TAG}_attn_occupancy.txt 2>&1; stamp attnocc; fi
 if has band; then  # tile-walk band width (knob bits 8..12 of the ablation mask) on the four GELU / dGELU shapes
   for i in 1 2; do
     for b in 3 4 12; do OCN_LIB_PATH=$DEVLIB timeout 200 python tools/ab_nt.py --knob $((b << 8)) --only gelu --json $O/${TAG}_band.jsonl >> $O/${TAG}_band$b.txt 2>&1; done
