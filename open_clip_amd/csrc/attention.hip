@@ -211,9 +211,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3))) void 
 // TWO_PASS: dV and dK in two sub-passes over the query blocks (S is recomputed in the second: +4 of 16 MFMAs per block) so that only ONE
 // pair of 32 x 64 accumulators is live at a time and each result leaves through the wave's own rows of the V image as soon as it is
 // complete -- the live set fits 168 registers (three waves per SIMD, six workgroups of two waves per CU instead of four) without spills.
-// ALIAS (developer build, timing only -- results WRONG): the dO image aliases the V image, i.e. the kernel runs with TWO images of LDS; with WPE = 4
-// (128 registers) eight 2-wave workgroups fit a CU instead of six: what a two-image / 128-register rebuild of this kernel could gain at most
-template <int MAXT, int WPE, bool TWO_PASS = false, bool ALIAS = false>
+template <int MAXT, int WPE, bool TWO_PASS = false>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, int causal,
@@ -241,8 +239,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
     // the dQ stores.
     char* sA = smem;                  // K, then Q, then the transposing buffer of dK
     char* sB = smem + LP * 128;       // V, then the transposing buffer of dQ
-    char* sC = ALIAS ? sB : smem + 2 * LP * 128;   // dO, then the transposing buffer of dV
-    float* sLse = (float*)(smem + (ALIAS ? 2 : 3) * LP * 128);
+    char* sC = smem + 2 * LP * 128;   // dO, then the transposing buffer of dV
+    float* sLse = (float*)(smem + 3 * LP * 128);
     float* sDelta = sLse + LP;
     const int lr = lane & 31, lh = lane >> 5;
     const float sc = scale * LOG2E;
@@ -646,17 +644,6 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
     // two-pass dK / dV build (168 registers, three waves per SIMD, no spills): developer knob 2 = 4 selects it, 2 = 5 forces the one-pass
     // build; default: see OCN_ATTN_BWD_TWO_PASS_DEFAULT
     const bool two_pass = g_ocn_tuning[2] == 4 || (g_ocn_tuning[2] != 5 && OCN_ATTN_BWD_TWO_PASS_DEFAULT && nw <= 4);
-#ifdef OCN_DEV_BUILD
-    if (nw <= 4 && g_ocn_tuning[2] >= 6) {  // developer timing probes (results wrong with 7): 6 = the shipped kernel held to 128 registers, 7 = + two LDS images
-        const int lds2 = 2 * nw * 32 * 128 + 2 * nw * 32 * 4;
-        if (g_ocn_tuning[2] == 6) hipLaunchKernelGGL((attn_bwd_kernel<256, 4, true, false>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
-        else hipLaunchKernelGGL((attn_bwd_kernel<256, 4, true, true>), dim3(nseq * H), dim3(nw * 64), lds2, st, (const bf16*)qkv,
-                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
-        OCN_CHECK_LAUNCH("ocn_attn_bwd");
-        return OCN_OK;
-    }
-#endif
     if (nw <= 4 && two_pass) {
         static bool attr_set = false;
         if (!attr_set) {

@@ -1,4 +1,8 @@
 """What more resident workgroups would buy the image tower's attention backward (developer tool; gpurun; OCN_LIB_PATH = the developer library).
+NOTE: the two probe instantiations this script selects (knob 2 = 6 / 7: `attn_bwd_kernel<256, 4, true, ALIAS>` in csrc/attention.hip, ALIAS = the dO image
+aliases the V image) existed in the tree only for the measurement of profiles/r05_attention_backward_occupancy_probe.txt (commit 'attention backward: the
+8-workgroups-per-CU route probed'); they were removed again so that the kernel sources -- and with them the hash the PMC traffic record is tied to -- stay those
+of the measured library.  With today's library knobs 6 / 7 select the shipped kernel.
 knob 2 = 0: shipped (two-pass, 158 registers, three LDS images: six 2-wave workgroups per CU); 6: the same kernel held to 128 registers (20 spilled; still six
 per CU: LDS-bound); 7: 128 registers AND two LDS images (dO aliases V: results WRONG, timing only): eight workgroups per CU."""
 import os
