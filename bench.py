@@ -96,6 +96,9 @@ def parse():
                     "that the default ViT-B-32 line carries as `config4_vitl14` / `config5_vith14_siglip` (each a subprocess of this file)")
     ap.add_argument("--dense-text", action="store_true", help="run all context_length positions of every caption through the text tower like the reference "
                     "does (default: packed -- only the tokens up to the pooled EOT exist; same features, loss and gradients, see model.py::_TextPack)")
+    ap.add_argument("--image-stream", default="fp32", choices=["fp32", "bf16", "bf16-fp32grad"],
+                    help="dtype of the IMAGE tower's residual stream: bf16 = what the reference's autocast runs there (transformer.py:794, layers.py:23-26; stream and "
+                         "its gradient in bf16), fp32 = the stricter native form, bf16-fp32grad = bf16 stream with an fp32 residual-gradient path")
     ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
     ap.add_argument("--naive-global-loss", action="store_true", help="N>1: every rank evaluates the full N x N logits (the reference's "
                     "redundant form) instead of its own rows (same loss and gradients; tests/test_dist_loss_gloo.py, test_ddp_gpu.py)")
@@ -108,7 +111,7 @@ def parse():
 NT_KERNEL = {0: "gemm_nt5_kernel<0,false,0> (plain bf16 out)", 1: "gemm_nt5_kernel<1,false,2> (bias + GELU, saves gelu' in 8 bits)",
              2: "gemm_nt5_kernel<2,false,8> (bias + fp32 residual)", 3: "gemm_nt5_kernel<3,false,10> (x saved 8-bit gelu')",
              4: "gemm_nt5_kernel<4,false,0> (fp32 out)", 5: "gemm_nt5_kernel<5,false,0> (logits: CE statistics)",
-             6: "gemm_nt5_kernel<6,false,0> (logits: CE gradient)"}
+             6: "gemm_nt5_kernel<6,false,0> (logits: CE gradient)", 8: "gemm_nt5_kernel<8,false,8> (bias + bf16 residual)"}
 
 
 class GemmTimer:
@@ -142,7 +145,7 @@ class GemmTimer:
             if epi == 3 and N < 1024:
                 name = "gemm_nt5_kernel<3,false,8> (x saved 8-bit gelu', N < 1024)"
             nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (4.0 if epi in (2, 4) else 2.0)  # A, B once; the output
-            nbytes += (4.0 * M * N if epi == 2 else 0.0) + (1.0 * M * N if epi in (1, 3) else 0.0)  # fp32 residual read; 8-bit gelu' written / read
+            nbytes += (4.0 * M * N if epi == 2 else 0.0) + (2.0 * M * N if epi == 8 else 0.0) + (1.0 * M * N if epi in (1, 3) else 0.0)  # fp32 / bf16 residual read; 8-bit gelu' written / read
             return timed("nt", name, 2.0 * M * N * K, nbytes, nt, epi, a, b, out, **kw)
 
         def gemm_tn(a, b, dw, dbias=None, *rest, **kw):
@@ -470,7 +473,7 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
     cfg = get_model_config(args.model)
     torch.manual_seed(0)
     extra = dict(init_logit_scale=math.log(10), init_logit_bias=-10.0) if args.siglip else {}  # main.py:259-261
-    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True, **extra)
+    model = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True, image_stream=args.image_stream, **extra)
     model.load_state_dict(init_state_dict(cfg, seed=0, siglip=args.siglip))
     model = model.to(dev).train()
     if args.dense_text:
@@ -735,6 +738,10 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
                                               if grad_sync is not None else ("DistributedDataParallel" if (world > 1 or args.force_ddp) else "none (one process)")),
                        "loss_collectives": ("C ABI (ocn_comm_*)" + (" on a one-rank communicator" if world == 1 else "")) if loss_comm is not None else ("torch.distributed" if world > 1 else "none"),
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
+                       "image_residual_stream": {"fp32": "fp32 (stricter than the reference's autocast)",
+                                                 "bf16": "bf16, stream and gradient (what the reference's autocast runs in the image tower: transformer.py:794, layers.py:23-26)",
+                                                 "bf16-fp32grad": "bf16 stream, fp32 residual-gradient path"}[args.image_stream],
+                       "text_residual_stream": "fp32 (as under the reference's autocast: the token embedding is fp32, model.py:399-401)",
                        "text_tower": text_rows_note,
                        "tower_streams": ("image tower on its own stream next to the text tower" if overlap_towers else "one stream"),
                        "last_block": last_block_note,

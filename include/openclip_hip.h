@@ -38,7 +38,9 @@ enum ocn_epilogue {
     OCN_EPI_BIAS_RESID_F32 = 2, /* out_f32 = resid_f32 + acc + bias                                       */
     OCN_EPI_DGELU = 3,          /* out_bf16 = acc * decode(aux_u8)   (aux = the gelu' saved by EPI 1)      */
     OCN_EPI_F32 = 4,            /* out_f32 = alpha*acc + bias                                             */
-    OCN_EPI_BIAS_QUICKGELU = 7  /* EPI 1 with QuickGELU, x * sigmoid(1.702 x) (layers.py:29-32; `quick_gelu` configs); (5, 6: internal) */
+    OCN_EPI_BIAS_QUICKGELU = 7, /* EPI 1 with QuickGELU, x * sigmoid(1.702 x) (layers.py:29-32; `quick_gelu` configs); (5, 6: internal) */
+    OCN_EPI_BIAS_RESID_BF16 = 8 /* out_bf16 = bf16(resid_bf16 + bf16(acc + bias)): the residual add on a bf16 stream exactly as the reference's
+                                   autocast evaluates it (F.linear's bf16 result, then `q_x + ...` in bf16: transformer.py:328-329) */
 };
 
 const char* ocn_last_error(void);
@@ -49,7 +51,9 @@ const char* ocn_last_error(void);
  *                  extra arguments in round 4, and the logit-gradient matrix G written by ocn_softmax_ce_rows / ocn_fused_logits_ce /
  *                  ocn_siglip_rows holds softmax (sigmoid) * grad_scale WITHOUT the -onehot term (the caller applies it as an exact rank-1
  *                  update: open_clip_amd/loss.py::_PairTerm.dX / dY). */
-#define OCN_ABI_VERSION 102
+/*   103 (round 6)  bf16 residual stream of the image tower: ocn_layernorm_fwd / ocn_layernorm_bwd / ocn_gather_rows take dtype flags, ocn_gemm_nt
+ *                  takes `resid` as void* (fp32 or bf16 by epilogue) and knows OCN_EPI_BIAS_RESID_BF16. */
+#define OCN_ABI_VERSION 103
 int ocn_version(void);
 
 /* ---- GEMMs (MFMA v_mfma_f32_32x32x16_bf16, fp32 accumulate) ------------------------------------
@@ -57,12 +61,12 @@ int ocn_version(void);
  *   (transformer.py:169 in_proj, :246 out_proj, :295-299 c_fc + nn.GELU + c_proj), the residual adds of
  *   transformer.py:328-329, `pooled @ proj` (:923), `x @ text_projection` (model.py:409), the logit
  *   matmul (loss.py:103-110) and every dgrad of the backward (a17).  K % 32 == 0; A, B bf16 row-major.
- *   bias [N] fp32 or NULL; resid fp32 [M,ldc] (EPI 2); aux uint8 [M,ldc] (EPI 1: written, EPI 3: read): the GELU derivative, the only
+ *   bias [N] fp32 or NULL; resid fp32 [M,ldc] (EPI 2) or bf16 [M,ldc] (EPI 8); aux uint8 [M,ldc] (EPI 1: written, EPI 3: read): the GELU derivative, the only
  *   thing the backward needs of the pre-activation, as q = round((gelu' + 0.13) * 200) in [0, 252] -- gelu' lies in [-0.129, 1.129], so
  *   the decoded value q / 200 - 0.13 is within 0.0025 of it (unbiased; rms 0.0014, what rounding a value in [0.5, 1) to bf16 costs) at
  *   half the bytes of a bf16 copy. */
 int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* out, int ldc, int M, int N, int K,
-                const float* bias, const float* resid, void* aux, float alpha, ocn_stream_t stream);
+                const float* bias, const void* resid, void* aux, float alpha, ocn_stream_t stream);
 
 /* ocn_gemm_tn_accum: dW[N,K] += alpha * A[M,N]^T . B[M,K]  (fp32 atomics into dW, which the caller zeroes or
  *   pre-loads); if dbias != NULL also dbias[N] += alpha * colsum(A).  The wgrad + bias-grad of every Linear
@@ -107,11 +111,15 @@ int ocn_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, ocn_s
  *      dcol (may be NULL): dcol[C] += sum_rows dx in fp32, before dx is rounded to bf16.  dx is the gradient of the output of the linear
  *      in front of this LayerNorm's input (out_proj, or the previous block's c_proj: transformer.py:246, :299), so this is that layer's bias
  *      gradient summed from fp32 values instead of from the bf16 operand of its weight-gradient GEMM.
- * ocn_colsum_f32: out[C] += sum_rows x[R, C] (fp32; the same for tensors no LayerNorm backward produces). */
-int ocn_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+ * ocn_colsum_f32: out[C] += sum_rows x[R, C] (fp32; the same for tensors no LayerNorm backward produces).
+ * bf16 residual stream (round 6; the IMAGE tower as the reference's autocast runs it: transformer.py:794 conv1 under autocast -> bf16,
+ *      layers.py:23-26 `x.to(orig_type)`): x is fp32 (x_is_bf16 = 0) or bf16 (1); in the backward a bf16 x takes a bf16 dy, no dcol, and the
+ *      residual gradient dres as bf16 (dres_is_bf16 = 1: the gradient of a bf16 tensor is bf16 under autograd) or fp32.  Statistics and
+ *      arithmetic are fp32 in every form. */
+int ocn_layernorm_fwd(const void* x, int x_is_bf16, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
                       float* rstd, int M, int C, float eps, ocn_stream_t stream);
-int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* w, const float* mean,
-                      const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw, float* db, float* dcol,
+int ocn_layernorm_bwd(const void* dy, int dy_is_f32, const void* x, int x_is_bf16, const float* w, const float* mean,
+                      const float* rstd, const void* dres, int dres_is_bf16, float* dx_f32, void* dx_bf16, float* dw, float* db, float* dcol,
                       float* det_workspace, int M, int C, ocn_stream_t stream);
 /* det_workspace (may be NULL = fp32 atomics): ocn_layernorm_bwd_det_workspace_floats(M, C) floats; the workgroups' partial dw / db / dcol rows go to
  * their own slabs and a second kernel adds them in workgroup order: bit-reproducible from run to run (torch.use_deterministic_algorithms) */
@@ -219,12 +227,13 @@ int ocn_token_embed_bwd_sorted_varlen(const int64_t* sorted_tokens, const int64_
  * gather_rows: out[b,:] = x[(b*L + idx[b]),:] (idx NULL -> token 0);  scatter_rows: dx (pre-zeroed)[b*L+idx[b],:] = d[b,:]
  *   (L = 0: idx holds absolute row numbers -- the packed text tower's last_row) */
 int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, ocn_stream_t stream);
-int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream);
+int ocn_gather_rows(const void* x, int x_is_bf16, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream); /* x fp32 or bf16; out fp32 */
 int ocn_gather_rows_bf16(const void* x, const int32_t* idx, void* out, int B, int L, int C, ocn_stream_t stream); /* bf16 x / out, C % 8 == 0 */
 int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C,
                      ocn_stream_t stream);
 /* dx[row_b] += d[b] (fp32), dx_bf16[row_b] = bf16 of the sum (may be NULL): the pooled rows' share of the last block's input gradient added
- * into the all-row LayerNorm backward's result instead of travelling through a zero [M, C] residual-gradient matrix */
+ * into the all-row LayerNorm backward's result instead of travelling through a zero [M, C] residual-gradient matrix.  dx = NULL (bf16
+ * gradient stream): dx_bf16[row_b] = bf16(dx_bf16[row_b] + d[b]). */
 int ocn_scatter_add_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C, ocn_stream_t stream);
 
 /* ---- F.normalize (model.py:391,411; eps 1e-12) -------------------------------------------------

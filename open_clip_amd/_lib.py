@@ -22,8 +22,8 @@ SIGNATURES = {
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
-    "ocn_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
-    "ocn_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ocn_layernorm_fwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "ocn_layernorm_bwd": [_p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "ocn_colsum_f32": [_p, _p, _i, _i, _i, _p],
     "ocn_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ocn_attn_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
@@ -47,7 +47,7 @@ SIGNATURES = {
     "ocn_token_embed_fwd_rows": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ocn_token_embed_bwd_sorted_varlen": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _i, _i, _i, _p],
     "ocn_argmax_rows": [_p, _p, _i, _i, _p],
-    "ocn_gather_rows": [_p, _p, _p, _i, _i, _i, _p],
+    "ocn_gather_rows": [_p, _i, _p, _p, _i, _i, _i, _p],
     "ocn_gather_rows_bf16": [_p, _p, _p, _i, _i, _i, _p],
     "ocn_scatter_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ocn_scatter_add_rows": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -83,7 +83,7 @@ DEBUG_SIGNATURES = {
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_det_workspace_bytes": ([_i, _i, _i], _l),
             "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l)}
 
-ABI_VERSION = 102  # == OCN_ABI_VERSION of include/openclip_hip.h (tests/test_cabi.py compares the two): load() refuses any other library
+ABI_VERSION = 103  # == OCN_ABI_VERSION of include/openclip_hip.h (tests/test_cabi.py compares the two): load() refuses any other library
 
 _lib = None
 _lock = threading.Lock()

@@ -382,7 +382,9 @@ __global__ void argmax_rows_kernel(const int64_t* __restrict__ text, int32_t* __
     if (lane == 0) idx[row] = bi;
 }
 
-__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, float* __restrict__ out,
+// X16: x is bf16 (the image tower's bf16 residual stream); the gathered rows are fp32 either way
+template <bool X16>
+__global__ void gather_rows_kernel(const void* __restrict__ x, const int32_t* __restrict__ idx, float* __restrict__ out,
                                    int B, int L, int C) {
     const int c4n = C / 4;
     const long total = (long)B * c4n;
@@ -390,7 +392,13 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* _
         const int c = (int)(i % c4n) * 4;
         const long b = i / c4n;
         const int t = idx ? idx[b] : 0;
-        *(f32x4*)(out + (size_t)b * C + c) = *(const f32x4*)(x + ((size_t)b * L + t) * C + c);
+        const size_t o = ((size_t)b * L + t) * C + c;
+        if constexpr (X16) {
+            const bf16x4 v = *(const bf16x4*)((const bf16*)x + o);
+            *(f32x4*)(out + (size_t)b * C + c) = (f32x4){bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+        } else {
+            *(f32x4*)(out + (size_t)b * C + c) = *(const f32x4*)((const float*)x + o);
+        }
     }
 }
 
@@ -422,8 +430,14 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ d, const int32
         const long b = i / c4n;
         const int t = idx ? idx[b] : 0;
         const size_t o = ((size_t)b * L + t) * C + c;
-        const f32x4 v = *(const f32x4*)(d + (size_t)b * C + c) + *(const f32x4*)(dx + o);
-        *(f32x4*)(dx + o) = v;
+        f32x4 v = *(const f32x4*)(d + (size_t)b * C + c);
+        if (dx) {
+            v = v + *(const f32x4*)(dx + o);
+            *(f32x4*)(dx + o) = v;
+        } else {  // bf16 gradient stream: the sum is formed on the bf16 value (rounded once more, on the B pooled rows only)
+            const bf16x4 h = *(const bf16x4*)(dx16 + o);
+            v = v + (f32x4){bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3])};
+        }
         if (dx16) {
             bf16x4 o4 = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             *(bf16x4*)(dx16 + o) = o4;
@@ -689,9 +703,10 @@ extern "C" int ocn_argmax_rows(const int64_t* text, int32_t* idx, int B, int L, 
     return OCN_OK;
 }
 
-extern "C" int ocn_gather_rows(const float* x, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream) {
+extern "C" int ocn_gather_rows(const void* x, int x_is_bf16, const int32_t* idx, float* out, int B, int L, int C, ocn_stream_t stream) {
     OCN_CHECK_ARG(x && out && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_gather_rows: bad arguments");
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, L, C);
+    if (x_is_bf16) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, L, C);
+    else hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, L, C);
     OCN_CHECK_LAUNCH("ocn_gather_rows");
     return OCN_OK;
 }
@@ -725,7 +740,7 @@ extern "C" int ocn_scatter_rows(const float* d, const int32_t* idx, float* dx, v
 }
 
 extern "C" int ocn_scatter_add_rows(const float* d, const int32_t* idx, float* dx, void* dx_bf16, int B, int L, int C, ocn_stream_t stream) {
-    OCN_CHECK_ARG(d && dx && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_scatter_add_rows: bad arguments");
+    OCN_CHECK_ARG(d && (dx || dx_bf16) && B > 0 && L >= 0 && (L > 0 || idx) && C % 4 == 0, "ocn_scatter_add_rows: bad arguments");
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long)B * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, d, idx, dx, (bf16*)dx_bf16, B, L, C);
     OCN_CHECK_LAUNCH("ocn_scatter_add_rows");
     return OCN_OK;

@@ -37,7 +37,9 @@ OCN_DEV void epilogue_store1(const GemmNtArgs& a, int gm, int gn, float v) {
         a.aux[o] = (unsigned char)(dgelu_q_bits(d1) & 255u);
         ((bf16*)a.out)[o] = f2bf(g1);
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
-        ((float*)a.out)[o] = v + b + a.resid[o];
+        ((float*)a.out)[o] = v + b + ((const float*)a.resid)[o];
+    } else if (EPI == OCN_EPI_BIAS_RESID_BF16) {  // the reference's autocast arithmetic: F.linear's result rounded to bf16, then the bf16 add
+        ((bf16*)a.out)[o] = f2bf(bf2f(f2bf(v + b)) + bf2f(((const bf16*)a.resid)[o]));
     } else if (EPI == OCN_EPI_DGELU) {
         ((bf16*)a.out)[o] = f2bf((v + b) * dgelu_unq(a.aux[o]));
     } else {
@@ -78,7 +80,7 @@ struct EpiBuf {
 // unconditional (address-clamped) loads: straight-line code lets the compiler keep counted vmcnt waits
 template <int EPI>
 OCN_DEV void epi_prefetch(const GemmNtArgs& a, int gm_base, int gn, int lane, EpiBuf<EPI>& b) {
-    if (EPI != OCN_EPI_BIAS_RESID_F32 && EPI != OCN_EPI_DGELU) return;
+    if (EPI != OCN_EPI_BIAS_RESID_F32 && EPI != OCN_EPI_BIAS_RESID_BF16 && EPI != OCN_EPI_DGELU) return;
     const int gnc = gn < a.N ? gn : a.N - 4;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -86,7 +88,10 @@ OCN_DEV void epi_prefetch(const GemmNtArgs& a, int gm_base, int gn, int lane, Ep
         gm = gm < a.M ? gm : a.M - 1;
         const size_t o = (size_t)gm * a.ldc + gnc;
         if (EPI == OCN_EPI_BIAS_RESID_F32) {
-            b.r[it] = *(const f32x4*)(a.resid + o);
+            b.r[it] = *(const f32x4*)((const float*)a.resid + o);
+        } else if (EPI == OCN_EPI_BIAS_RESID_BF16) {
+            const bf16x4 h = *(const bf16x4*)((const bf16*)a.resid + o);
+            b.r[it] = (f32x4){bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3])};
         } else {
             b.r[it] = dgelu_unpack4(*(const unsigned*)(a.aux + o));
         }
@@ -114,6 +119,9 @@ OCN_DEV void epi_apply_store(const GemmNtArgs& a, int gm, int gn, f32x4 v, f32x4
         *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_BIAS_RESID_F32) {
         *(f32x4*)((float*)a.out + o) = v + extra;
+    } else if (EPI == OCN_EPI_BIAS_RESID_BF16) {
+        bf16x4 o4 = {f2bf(bf2f(f2bf(v[0])) + extra[0]), f2bf(bf2f(f2bf(v[1])) + extra[1]), f2bf(bf2f(f2bf(v[2])) + extra[2]), f2bf(bf2f(f2bf(v[3])) + extra[3])};
+        *(bf16x4*)((bf16*)a.out + o) = o4;
     } else if (EPI == OCN_EPI_DGELU) {
         bf16x4 o4 = {f2bf(v[0] * extra[0]), f2bf(v[1] * extra[1]), f2bf(v[2] * extra[2]), f2bf(v[3] * extra[3])};
         *(bf16x4*)((bf16*)a.out + o) = o4;
@@ -437,14 +445,14 @@ int launch_nt(const GemmNtArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, int ldb, void* out, int ldc, int M, int N,
-                           int K, const float* bias, const float* resid, void* aux, float alpha, ocn_stream_t stream) {
+                           int K, const float* bias, const void* resid, void* aux, float alpha, ocn_stream_t stream) {
     OCN_CHECK_ARG(A && B && out, "ocn_gemm_nt: null operand");
     OCN_CHECK_ARG(M > 0 && N > 0 && K > 0, "ocn_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
     OCN_CHECK_ARG(K % 32 == 0, "ocn_gemm_nt: K=%d must be a multiple of 32", K);
     OCN_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "ocn_gemm_nt: bad leading dims");
     OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)out & 15) == 0,
                   "ocn_gemm_nt: operands must be 16-byte aligned");
-    OCN_CHECK_ARG(epilogue != OCN_EPI_BIAS_RESID_F32 || resid, "ocn_gemm_nt: residual epilogue needs resid");
+    OCN_CHECK_ARG((epilogue != OCN_EPI_BIAS_RESID_F32 && epilogue != OCN_EPI_BIAS_RESID_BF16) || resid, "ocn_gemm_nt: residual epilogue needs resid");
     OCN_CHECK_ARG((epilogue != OCN_EPI_BIAS_GELU && epilogue != OCN_EPI_BIAS_QUICKGELU && epilogue != OCN_EPI_DGELU) || aux, "ocn_gemm_nt: gelu epilogues need aux");
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (unsigned char*)aux;
@@ -456,6 +464,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
         case OCN_EPI_BIAS_GELU: return launch_nt<OCN_EPI_BIAS_GELU>(a, st);
         case OCN_EPI_BIAS_QUICKGELU: return launch_nt<OCN_EPI_BIAS_QUICKGELU>(a, st);
         case OCN_EPI_BIAS_RESID_F32: return launch_nt<OCN_EPI_BIAS_RESID_F32>(a, st);
+        case OCN_EPI_BIAS_RESID_BF16: return launch_nt<OCN_EPI_BIAS_RESID_BF16>(a, st);
         case OCN_EPI_DGELU: return launch_nt<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch_nt<OCN_EPI_F32>(a, st);
     }

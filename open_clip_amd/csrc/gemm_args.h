@@ -7,7 +7,7 @@ struct GemmNtArgs {
     const bf16* B;
     void* out;
     const float* bias;
-    const float* resid;
+    const void* resid;  // fp32 (OCN_EPI_BIAS_RESID_F32) or bf16 (OCN_EPI_BIAS_RESID_BF16) [M, ldc]
     unsigned char* aux;  // saved gelu' in 8 bits (ocn_common.h: dgelu_pack4 / dgelu_unpack4), [M, ldc] bytes
     int lda, ldb, ldc, M, N, K;
     float alpha;

@@ -97,9 +97,11 @@ OCN_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, long row0, int rows_t
 //             4 bytes per lane = 32-byte row segments, from inside the epilogue: the PMC pass showed the saved derivatives crossing the
 //             L2 -> fabric boundary 1.85 times, and the first wait of every tile sat on a full HBM round trip.)
 //   residual  the fp32 residual rows of the first two 32 x 32 blocks = slots 0 and 1 of the epilogue's operand ring
+//   bf16 residual (round 6)  the bf16 residual rows of the first two 32 x 64 sub-blocks of the wave's strip, 16 bytes (8 columns) per lane in the
+//             layout of the epilogue's row-wise stores; the other two are requested by the epilogue as it frees these registers
 template <int EPI>
 struct NtPf {
-    static constexpr int N = (EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32) ? 8 : 0;
+    static constexpr int N = (EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_BIAS_RESID_BF16) ? 8 : 0;
 };
 
 // byte offset of this lane's 4 fp32 columns in row it*8 + (lane >> 3) of 32 x 32 block blk (fp32-staged epilogues, residual prefetch)
@@ -123,6 +125,15 @@ OCN_DEV void epi_prefetch(const GemmNtArgs& a, int m0, int n0, int row_w, int wn
             const unsigned base = (unsigned)((row_w + (lane_o >> 2)) * a.ldc + gn) | (gn < a.N ? 0u : OOB);
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = __builtin_amdgcn_raw_buffer_load_b128(r_aux, base + (unsigned)(j * 16 * a.ldc), 0, (AUX & 8) ? 2 : 0);
+        } else if constexpr (EPI == OCN_EPI_BIAS_RESID_BF16) {
+            const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 2);
+            const int gn = gn_w + (lane_o & 7) * 8;
+            const unsigned col_off = gn < a.N ? (unsigned)gn * 2u : OOB;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    pf[sb * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (unsigned)((row_w + sb * 32 + it * 8 + (lane_o >> 3)) * a.ldc) * 2u + col_off, 0, (AUX & 8) ? 2 : 0);
         } else {
             const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 4);
 #pragma unroll
@@ -163,7 +174,8 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const unsigned rd_addr = stg + rd_row * 128 + ((rd_chunk ^ rd_row) << 4);  // + it * 1024 for rows it*8 + rd_row
     constexpr bool IS_GELU = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);  // two-output activation epilogues
     constexpr bool IS_DGELU = (EPI == OCN_EPI_DGELU);
-    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || EPI == OCN_EPI_CE_GRAD);
+    constexpr bool IS_RES16 = (EPI == OCN_EPI_BIAS_RESID_BF16);  // bf16 residual stream: out = bf16(resid + bf16(acc + bias)), added behind the transpose
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || IS_RES16 || EPI == OCN_EPI_CE_GRAD);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     // developer knobs 32 / 128 (OCN_DEV_BUILD only): zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued
     // but the bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
@@ -177,7 +189,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const long m_win = win ? (long)((blockIdx.x * 65536L) / ((long)a.ldc * (OUT_F32 ? 4 : 2))) : m0;
     const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m_win, m_st, a.ldc, OUT_F32 ? 4 : 2);
     const __amdgpu_buffer_rsrc_t r_aux = aux_is_out ? tile_rsrc(a.aux, m_win, m_st, a.ldc, 1) : tile_rsrc(a.aux, m0, m_ld, a.ldc, 1);  // gelu' in 8 bits
-    const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, 4);
+    const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, IS_RES16 ? 2 : 4);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
     // Bias is fetched ONCE, before any store of this tile is issued (a later load would have to wait behind the stores):
     // bf16-staged epilogues add it in the accumulator layout (before rounding), fp32-staged ones after the transpose.
@@ -294,7 +306,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[ha][s][hb][4 * g], acc[ha][s][hb][4 * g + 1], acc[ha][s][hb][4 * g + 2], acc[ha][s][hb][4 * g + 3]};
-                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else if (IS_GELU) v = v + bv[hb][g];
+                        if (EPI == OCN_EPI_BF16) v = v * a.alpha + bv[hb][g]; else if (IS_GELU || IS_RES16) v = v + bv[hb][g];
                         if (IS_DGELU) v = v * dgelu_unpack4(dq[hb][g]);  // gelu'(pre-activation), saved by the forward epilogue
                         if (IS_GELU) {
                             f32x4 gv = v, dv = v;  // (developer knob 1: skip the VALU work)
@@ -348,6 +360,27 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                         for (int g = 0; g < 4; ++g) lds_w64(stg + lr * 128 + (((hb * 4 + g) ^ (lr & 7)) << 4) + lh * 8, pk[hb][g]);
                     bf16x8 d[4];
                     lds_r128x4(rd_addr, rd_addr + 1024, rd_addr + 2048, rd_addr + 3072, d[0], d[1], d[2], d[3]);
+                    if constexpr (IS_RES16) {
+                        // the residual rows arrive in the layout of the stores: sub-blocks 0 / 1 with the main loop's prefetch, 2 / 3 requested here, as soon as
+                        // the registers of sub-block sb are free and BEFORE its stores are issued (vmcnt retires in issue order: the wait for sub-block sb + 2's
+                        // rows then covers the stores of sub-block sb - 1 at most, never the ones just issued)
+                        const int sb = ha * 2 + s;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const bf16x8 rr = __builtin_bit_cast(bf16x8, pf[(sb & 1) * 4 + it]);
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(d[it][e]) + bf2f(rr[e]));
+                            d[it] = o;
+                        }
+                        if (sb + 2 < 2 * ha_n) {
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) {
+                                const int row = row_w + (ha + 1) * 64 + s * 32 + it * 8 + rd_row;
+                                pf[(sb & 1) * 4 + it] = __builtin_amdgcn_raw_buffer_load_b128(r_res, (unsigned)(row * a.ldc) * 2u + col_off, 0, (AUX & 8) ? 2 : 0);
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int row = row_w + ha * 64 + s * 32 + it * 8 + rd_row;
@@ -855,7 +888,7 @@ template <int EPI>
 int nt5_stagger(int ntiles, int K, int forced) {
     if (forced == 0 || forced == 63) return 0;
     if (forced != 62) return forced * 100;
-    constexpr bool heavy = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU || EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
+    constexpr bool heavy = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU || EPI == OCN_EPI_DGELU || EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_BIAS_RESID_BF16 || EPI == OCN_EPI_F32);
     if (!heavy || ntiles < 12 * g_num_cu) return 0;
     const int tile_us = (K / 64) * 2 + 6;
     return tile_us * 100 / 4;
@@ -923,7 +956,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     //   loads:  non-temporal for the fp32 residual and the saved gelu' -- both read exactly once.
     constexpr bool is_gelu = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);
     const bool st_nt = is_gelu || ((EPI == OCN_EPI_BF16 || EPI == OCN_EPI_DGELU) && a.N >= 1024);
-    const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_DGELU);
+    const bool ld_nt = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_BIAS_RESID_BF16 || EPI == OCN_EPI_DGELU);
 #ifdef OCN_DEV_BUILD
     if (a.ablate & 64) {  // per-tile timeline into g_nt5_trace (tools/gemm_trace.py)
         static bool dbg_attr_set = false;
@@ -950,7 +983,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
 #else
     // the product library holds exactly the instantiations the rules above select
     if constexpr (is_gelu) return launch5_aux<EPI, 2>(a, grid, st);
-    else if constexpr (EPI == OCN_EPI_BIAS_RESID_F32) return launch5_aux<EPI, 8>(a, grid, st);
+    else if constexpr (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_BIAS_RESID_BF16) return launch5_aux<EPI, 8>(a, grid, st);
     else if constexpr (EPI == OCN_EPI_DGELU) return st_nt ? launch5_aux<EPI, 10>(a, grid, st) : launch5_aux<EPI, 8>(a, grid, st);
     else if constexpr (EPI == OCN_EPI_BF16) return st_nt ? launch5_aux<EPI, 2>(a, grid, st) : launch5_aux<EPI, 0>(a, grid, st);
     else return launch5_aux<EPI, 0>(a, grid, st);
@@ -979,6 +1012,7 @@ int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
         case OCN_EPI_BIAS_GELU: return launch5<OCN_EPI_BIAS_GELU>(a, st);
         case OCN_EPI_BIAS_QUICKGELU: return launch5<OCN_EPI_BIAS_QUICKGELU>(a, st);
         case OCN_EPI_BIAS_RESID_F32: return launch5<OCN_EPI_BIAS_RESID_F32>(a, st);
+        case OCN_EPI_BIAS_RESID_BF16: return launch5<OCN_EPI_BIAS_RESID_BF16>(a, st);
         case OCN_EPI_DGELU: return launch5<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch5<OCN_EPI_F32>(a, st);
         case OCN_EPI_CE_STATS: return launch5<OCN_EPI_CE_STATS>(a, st);

@@ -7,7 +7,11 @@ checkpoints load with ``load_state_dict``.  Modules here are *parameter containe
 ``torch.autograd.Function``s that enqueue hand-written gfx950 kernels through the C ABI (``ops.py``).
 
 Precision policy (mirrors ``--precision amp_bf16``, precision.py:6-16): fp32 master weights, bf16 GEMM /
-attention operands with fp32 accumulation, fp32 residual stream, fp32 LayerNorm / softmax / loss statistics.
+attention operands with fp32 accumulation, fp32 LayerNorm / softmax / loss statistics.  Residual stream: fp32 in the text tower (what autocast
+leaves there: the token embedding is fp32, model.py:399-401); in the image tower fp32 (``image_stream="fp32"``, the stricter default) or bf16
+(``image_stream="bf16"``) -- what the reference's own autocast produces there: conv1 runs under autocast (transformer.py:794 -> bf16), LayerNorm
+casts back to its input dtype (layers.py:23-26) and `q_x + attention(...)` adds two bf16 tensors, so the reference's image stream AND its
+gradient are bf16.
 Autograd granularity is one Function per residual block, so gradients reach ``.grad`` (and DDP's bucket hooks)
 block by block while the backward is still running, and block-granular recompute (``set_grad_checkpointing``)
 is a flag of the same Function.
@@ -39,6 +43,9 @@ class _WeightCache:
         self.single_query = True  # pooled last block (head_dim 64): K, V projection only + single-query attention (_pooled_block_forward)
         self._side = _StreamMap()  # wgrad side streams of this tower, one per (device, main stream)
         self.twin_stats = {"hit": 0, "miss": 0}  # how often a block's backward found the bf16 twin of its incoming gradient (tests assert it does)
+        # residual stream of THIS tower: "fp32" | "bf16" (stream and its gradient bf16: the reference's autocast in the image tower) |
+        # "bf16-fp32grad" (bf16 stream; the gradient travels as bf16 with an fp32 companion for the residual path, see _publish_f32)
+        self.stream = "fp32"
 
     def side_stream(self, dev):
         """the wgrad stream that belongs to the CURRENT stream (one per main stream: the towers may run on streams of their own)"""
@@ -79,7 +86,7 @@ class _WeightCache:
         """a copied model (EMA twin, base_task.py:171) has new parameter addresses: none of the cached operand copies could ever hit
         there, so the copy starts empty instead of duplicating every bf16 weight"""
         new = _WeightCache()
-        new.pair_wgrad, new.deterministic, new.single_query = self.pair_wgrad, self.deterministic, self.single_query
+        new.pair_wgrad, new.deterministic, new.single_query, new.stream = self.pair_wgrad, self.deterministic, self.single_query, self.stream
         return new
 
 
@@ -103,6 +110,19 @@ def _publish_twin(g32, g16, colsum=None):
 def _take_colsum(g32):
     cs = getattr(g32, "_ocn_colsum", None)
     return cs[0] if (cs is not None and cs[1] == g32._version and cs[0].device == g32.device) else None
+
+
+def _publish_f32(g16, g32, colsum=None):
+    """bf16 residual stream (image tower): the OFFICIAL gradient between two blocks is the bf16 tensor (autograd hands a bf16 tensor's gradient on in
+    bf16, and it is the dgrad / wgrad GEMMs' operand as it stands); ``image_stream="bf16-fp32grad"`` lets the fp32 value the LayerNorm backward had in
+    registers travel beside it for the residual path -- the same attribute mechanism as the twin above, in the other direction"""
+    g16._ocn_f32 = (g32, g16._version) if g32 is not None else None
+    g16._ocn_colsum = (colsum, g16._version) if colsum is not None else None
+
+
+def _take_f32(g16):
+    c = getattr(g16, "_ocn_f32", None)
+    return c[0] if (c is not None and c[1] == g16._version and c[0].shape == g16.shape and c[0].device == g16.device) else None
 
 
 def _take_twin(g32, cache=None):
@@ -208,12 +228,15 @@ def _block_forward(x, p, cache, B, L, heads, causal, seq_off=None, act=ops.EPI_B
     qkv = ops.gemm_nt(ops.EPI_BF16, h1, cache.get(wqkv, "n"), ops.empty((M, 3 * C), BF16, x), bias=bqkv)
     hd = C // heads
     a, lse = ops.attn_fwd(qkv, B, L, heads, causal, hd ** -0.5, hd, seq_off)
-    xmid = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, a, cache.get(wo, "n"), ops.empty((M, C), F32, x), bias=bo, resid=x)
+    # the residual stream keeps the dtype it arrives in: fp32, or bf16 (image tower, ``image_stream="bf16"``: LayerNorm reads bf16, the residual
+    # epilogue adds in bf16 as the reference's autocast does -- ops.EPI_BIAS_RESID_BF16)
+    epi_res = ops.EPI_BIAS_RESID_BF16 if x.dtype == BF16 else ops.EPI_BIAS_RESID_F32
+    xmid = ops.gemm_nt(epi_res, a, cache.get(wo, "n"), ops.empty((M, C), x.dtype, x), bias=bo, resid=x)
     h2, _, mean2, rstd2 = ops.layernorm_fwd(xmid, ln2w, ln2b)
     Fd = wfc.shape[0]
     f = ops.empty((M, Fd), torch.uint8, x)  # gelu'(pre-activation) in 8-bit fixed point: all the backward needs of it
     g = ops.gemm_nt(act, h2, cache.get(wfc, "n"), ops.empty((M, Fd), BF16, x), bias=bfc, aux=f)  # act: erf GELU or QuickGELU epilogue
-    y = ops.gemm_nt(ops.EPI_BIAS_RESID_F32, g, cache.get(wproj, "n"), ops.empty((M, C), F32, x), bias=bproj, resid=xmid)
+    y = ops.gemm_nt(epi_res, g, cache.get(wproj, "n"), ops.empty((M, C), x.dtype, x), bias=bproj, resid=xmid)
     return y, (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g)
 
 
@@ -243,9 +266,16 @@ class _BlockFn(torch.autograd.Function):
         (mean1, rstd1, h1, qkv, a, lse, xmid, mean2, rstd2, h2, f, g) = saved
         M, C = x.shape
         Fd = wfc.shape[0]
-        dy16 = _take_twin(dy, cache)
+        bf = x.dtype == BF16  # bf16 residual stream: dy IS the bf16 GEMM operand; the residual path adds it in bf16 (or from its fp32 companion)
+        keep32 = bf and cache.stream == "bf16-fp32grad"
         dy_colsum = _take_colsum(dy)  # only the head publishes one (B rows: free): the LAST block's c_proj bias gradient as an fp32 column sum
-        dy = dy.contiguous()
+        if bf:
+            dy16 = dy.contiguous()
+            dy = (_take_f32(dy) if keep32 else None)
+            dy = dy16 if dy is None else dy
+        else:
+            dy16 = _take_twin(dy, cache)
+            dy = dy.contiguous()
         # one zeroed fp32 arena for all of the block's parameter gradients (wgrad kernels accumulate atomically)
         grads = _grad_arena(p)
         (dln1w, dln1b, dwqkv, dbqkv, dwo, dbo, dln2w, dln2b, dwfc, dbfc, dwproj, dbproj) = grads
@@ -267,7 +297,7 @@ class _BlockFn(torch.autograd.Function):
         with _Paired(dev, cache, pair) as side:
             if need_w:
                 side(ops.gemm_tn_accum, dy16, g, dwproj, None if dy_colsum is not None else dbproj, 1.0, det)
-            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
+            dxmid, dxmid16 = ops.layernorm_bwd(dh2, xmid, ln2w, mean2, rstd2, dln2w, dln2b, dres=dy, want_f32=(not bf or keep32), want_bf16=True, deterministic=cache.deterministic)
         # ---- attention branch: x_mid = x + out_proj(attn(in_proj(ln_1(x)))) ----
         da = ops.gemm_nt(ops.EPI_BF16, dxmid16, cache.get(wo, "t"), ops.empty((M, C), BF16, x))
         with _Paired(dev, cache, pair) as side:
@@ -281,8 +311,13 @@ class _BlockFn(torch.autograd.Function):
                 side(ops.gemm_tn_accum, dqkv, h1, dwqkv, dbqkv, 1.0, True)
             elif need_w:  # out-proj and QKV wgrads share their rows and their K = C: one launch (36 tiles, 7 M-splits instead of 28 + 9)
                 side(ops.gemm_tn_accum2, dxmid16, a, dwo, dbo, dqkv, h1, dwqkv, dbqkv)
-            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dxmid, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
-        _publish_twin(dx, dx16)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=(dxmid if dxmid is not None else dxmid16), want_f32=(not bf or keep32),
+                                         want_bf16=True, deterministic=cache.deterministic)
+        if bf:
+            _publish_f32(dx16, dx)
+            dx = dx16
+        else:
+            _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None, None)
@@ -401,16 +436,22 @@ class _PooledBlockFn(torch.autograd.Function):
             if need_w:
                 ops.gemm_tn_accum(dqkv, h1, dwqkv, dbqkv, 1.0, det)
             dxp = None
+        bf = x.dtype == BF16  # bf16 residual stream below this block: its input gradient leaves as bf16 (see _BlockFn.backward)
+        keep32 = bf and cache.stream == "bf16-fp32grad"
         if dxp is not None:
-            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, want_f32=(not bf or keep32), want_bf16=True, deterministic=cache.deterministic)
             ops.scatter_add_rows(dxp, rows, dx, B, 0, dx16)
         else:
             # the all-query form keeps the full block's arithmetic to the bit (the residual gradient enters INSIDE the LayerNorm backward, where the
             # compiler contracts it into an FMA): it is the form tests/test_model_gpu.py::test_pooled_last_block_equals_full_block proves exact
             dres = torch.zeros((M, C), dtype=F32, device=x.device)
             ops.scatter_rows(dxmid_p, rows, dres, B, 0, None)  # the residual path x -> xmid carries gradient on the pooled rows only
-            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=True, want_bf16=True, deterministic=cache.deterministic)
-        _publish_twin(dx, dx16)
+            dx, dx16 = ops.layernorm_bwd(dh1, x, ln1w, mean1, rstd1, dln1w, dln1b, dres=dres, want_f32=(not bf or keep32), want_bf16=True, deterministic=cache.deterministic)
+        if bf:
+            _publish_f32(dx16, dx)
+            dx = dx16
+        else:
+            _publish_twin(dx, dx16)
         if not need_w:
             grads = [None] * 12
         return (dx, *grads, None, None, None, None, None, None, None, None, None)
@@ -441,7 +482,9 @@ class _VisionEmbedFn(torch.autograd.Function):
             w16[:, :KP].copy_(cache.get(conv_w, "n"))
         po = ops.gemm_nt(ops.EPI_F32, patches, w16, ops.empty((B * G, width), F32, patches))
         emb = ops.embed_assemble_fwd(po, cls, pos, B, G, width)
-        _, x0, mean, rstd = ops.layernorm_fwd(emb, lnw, lnb, want_bf16=False, want_f32=True)
+        bf = cache.stream != "fp32"  # bf16 residual stream: ln_pre hands its result on in bf16 (layers.py:23-26 under autocast); emb itself stays fp32 here
+        x16, x0, mean, rstd = ops.layernorm_fwd(emb, lnw, lnb, want_bf16=bf, want_f32=not bf)
+        x0 = x16 if bf else x0
         ctx.save_for_backward(patches, emb, mean, rstd, lnw, conv_w, cls, pos)
         ctx.meta = (B, G, width, KP, Kpad)
         ctx.cache = cache
@@ -453,7 +496,8 @@ class _VisionEmbedFn(torch.autograd.Function):
         B, G, width, KP, Kpad = ctx.meta
         dev = emb.device
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
-        dy0 = dx0.contiguous()
+        dy0 = (_take_f32(dx0) if dx0.dtype == BF16 else None)  # bf16 stream: the first block's fp32 companion when there is one
+        dy0 = dx0.contiguous() if dy0 is None else dy0
         demb, _ = ops.layernorm_bwd(dy0, emb, lnw, mean, rstd, dlnw, dlnb, want_f32=True, deterministic=ctx.cache.deterministic)
         dpos, dcls = torch.zeros_like(pos), torch.zeros_like(cls)
         dpatch = ops.embed_assemble_bwd(demb, dpos, dcls, B, G, width, ctx.cache.deterministic)
@@ -556,13 +600,13 @@ class _HeadFn(torch.autograd.Function):
         else:
             y, inv = feat, None
         ctx.save_for_backward(pooled, p16, mean, rstd, lnw, proj, idx, y, inv)
-        ctx.meta = (cache, B, L, normalize, x.shape)
+        ctx.meta = (cache, B, L, normalize, x.shape, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         pooled, p16, mean, rstd, lnw, proj, idx, y, inv = ctx.saved_tensors
-        cache, B, L, normalize, xshape = ctx.meta
+        cache, B, L, normalize, xshape, xdtype = ctx.meta
         dy = dy.contiguous().float()
         dfeat = ops.l2norm_bwd(dy, y, inv) if normalize else dy
         dfeat16 = ops.cast_bf16(dfeat)
@@ -574,8 +618,12 @@ class _HeadFn(torch.autograd.Function):
         dlnw, dlnb = torch.zeros_like(lnw), torch.zeros_like(lnw)
         dcol = torch.zeros_like(lnw)  # column sums of dpooled = of dx (zero elsewhere): the last block's c_proj bias gradient, in fp32
         dpooled, _ = ops.layernorm_bwd(dp32, pooled, lnw, mean, rstd, dlnw, dlnb, want_f32=True, dcol=dcol, deterministic=cache.deterministic)
-        dx = torch.zeros(xshape, dtype=F32, device=dy.device)
         dx16 = torch.zeros(xshape, dtype=BF16, device=dy.device)  # bf16 twin for the last block's dgrad / wgrad GEMMs
+        if xdtype == BF16:  # all rows of a bf16 residual stream (full last block): the gradient itself is the bf16 tensor
+            ops.scatter_rows(dpooled, idx, None, B, L, dx16)
+            _publish_f32(dx16, None, dcol)
+            return dx16, dlnw, dlnb, dproj, None, None, None, None, None
+        dx = torch.zeros(xshape, dtype=F32, device=dy.device)
         ops.scatter_rows(dpooled, idx, dx, B, L, dx16)
         _publish_twin(dx, dx16, dcol)
         return dx, dlnw, dlnb, dproj, None, None, None, None, None
@@ -830,7 +878,7 @@ class NativeCLIP(nn.Module):
 
     def __init__(self, embed_dim, vision_cfg, text_cfg, init_logit_scale=math.log(1 / 0.07), init_logit_bias=None,
                  output_dict=False, *, pack_text=True, tower_streams=True, pooled_last_block=True, attn_buckets=True, pair_wgrad=True,
-                 deterministic=False, quick_gelu=False, **model_kwargs):
+                 deterministic=False, quick_gelu=False, image_stream="fp32", **model_kwargs):
         """Reference arguments first (model.py:318-365).  Keyword-only switches of the native execution (every one also a plain attribute
         that may be flipped later; none changes a result beyond fp32 summation order):
         ``pack_text`` -- the text tower holds only the tokens up to the pooled EOT (_TextPack); ``tower_streams`` -- image tower on a
@@ -839,8 +887,13 @@ class NativeCLIP(nn.Module):
         attention launches grouped by 32-row block count; ``pair_wgrad`` -- in one-stream mode, the blocks' wgrad GEMMs on a side
         stream under the HBM-bound kernels; ``deterministic`` -- every weight / bias gradient GEMM in its reproducible form (per-split
         slabs summed in a fixed order instead of fp32 atomics: 98 % of the gradient elements; the LayerNorm-affine, embedding and
-        scalar-loss reductions still accumulate with fp32 atomics)."""
+        scalar-loss reductions still accumulate with fp32 atomics).
+        ``image_stream`` DOES change results, inside the stated tolerances: the dtype of the IMAGE tower's residual stream -- "fp32" (default; stricter than
+        the reference), "bf16" (stream and its gradient in bf16 = what the reference's autocast produces there, transformer.py:794 + layers.py:23-26;
+        half the residual-stream bytes of 24 residual epilogues and 49 LayerNorm passes) or "bf16-fp32grad" (bf16 stream, fp32 residual-gradient path)."""
         super().__init__()
+        if image_stream not in ("fp32", "bf16", "bf16-fp32grad"):
+            raise ValueError(f"image_stream must be 'fp32', 'bf16' or 'bf16-fp32grad' (got {image_stream!r})")
         v, t = dict(vision_cfg), dict(text_cfg)
         self._check_cfg(v, t, model_kwargs)
         self.output_dict = output_dict
@@ -884,6 +937,7 @@ class NativeCLIP(nn.Module):
         self.pooled_single_query = True
         self.deterministic = bool(deterministic)
         self.pair_wgrad = bool(pair_wgrad)  # one-stream mode: the blocks' wgrad GEMMs on a side stream under the HBM-bound kernels (_Paired)
+        self.image_stream = image_stream  # residual-stream dtype of the image tower (see the docstring); a plain attribute like the other switches
         self.init_parameters()
         # the bf16 operand copies are keyed by (address, version counter); writes through ``.data`` (checkpoint loading, EMA swaps,
         # manual re-initialisation) do not move the counter, so every load_state_dict drops them
@@ -949,8 +1003,9 @@ class NativeCLIP(nn.Module):
         v, t = self.visual, self.transformer
         rows_v = batch_size * (v.grid_size[0] * v.grid_size[1] + 1)
         rows_t = batch_size * self.context_length if text_rows is None else int(text_rows)
-        per = lambda rows, tr: rows * (20 * tr.width + 3 * tr.resblocks[0].mlp.c_fc.out_features + 4 * tr.resblocks[0].n_head + 8)
-        return per(rows_v, v.transformer), per(rows_t, t)
+        per = lambda rows, tr, sb: rows * ((12 + 2 * sb) * tr.width + 3 * tr.resblocks[0].mlp.c_fc.out_features + 4 * tr.resblocks[0].n_head + 8)
+        # sb = bytes per element of the tower's residual stream: the block output and the middle of the stream are saved in that dtype
+        return per(rows_v, v.transformer, 2 if self.image_stream != "fp32" else 4), per(rows_t, t, 4)
 
     def plan_grad_checkpointing(self, batch_size: int, budget_bytes: int, text_rows=None):
         """switch block recompute on and keep the activations of as many blocks as ``budget_bytes`` hold: the text tower's first (few
@@ -974,10 +1029,12 @@ class NativeCLIP(nn.Module):
         self._cache.pair_wgrad = self.visual._cache.pair_wgrad = self.pair_wgrad and not overlap
         self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
         self._cache.single_query = self.visual._cache.single_query = bool(self.pooled_single_query)
+        self.visual._cache.stream = self.image_stream
 
     def encode_image(self, image, normalize: bool = False):
         self._cache.deterministic = self.visual._cache.deterministic = self.deterministic
         self.visual._cache.single_query = bool(self.pooled_single_query)
+        self.visual._cache.stream = self.image_stream
         return self.visual(image, normalize)
 
     def encode_text(self, text, normalize: bool = False, _pack=None):

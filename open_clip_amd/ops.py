@@ -10,6 +10,7 @@ from . import _lib
 
 EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID_F32, EPI_DGELU, EPI_F32 = 0, 1, 2, 3, 4
 EPI_BIAS_QUICKGELU = 7  # EPI_BIAS_GELU with x * sigmoid(1.702 x) (layers.py:29-32); its backward is the same EPI_DGELU
+EPI_BIAS_RESID_BF16 = 8  # out bf16 = bf16(resid bf16 + bf16(acc + bias)): the residual add on the image tower's bf16 stream (as the reference's autocast)
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -49,6 +50,7 @@ def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
     pa, lda = _chk2d(a, BF16, "a")
     pb, ldb = _chk2d(b, BF16, "b")
     odt = F32 if epi in (EPI_BIAS_RESID_F32, EPI_F32) else BF16
+    rdt = BF16 if epi == EPI_BIAS_RESID_BF16 else F32
     po, ldc = _chk2d(out, odt, "out")
     M, K = a.shape
     N = b.shape[0]
@@ -59,7 +61,7 @@ def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
     if aux is not None and (aux.shape != out.shape or aux.stride(0) != ldc):
         raise RuntimeError("gemm_nt: aux must match out")
     _lib.call("ocn_gemm_nt", epi, pa, lda, pb, ldb, po, ldc, M, N, K, _chk(bias, F32, "bias"),
-              0 if resid is None else _chk2d(resid, F32, "resid")[0], 0 if aux is None else _chk2d(aux, torch.uint8, "aux")[0],
+              0 if resid is None else _chk2d(resid, rdt, "resid")[0], 0 if aux is None else _chk2d(aux, torch.uint8, "aux")[0],
               float(alpha), _stream())
     return out
 
@@ -140,11 +142,13 @@ def cast_transpose_bf16(src, out=None):
 
 # ---- LayerNorm -----------------------------------------------------------------------------------------
 def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
+    """``x`` fp32 or bf16 (the image tower's bf16 residual stream); statistics and arithmetic are fp32 either way"""
     M, C = x.shape
     y16 = empty((M, C), BF16, x) if want_bf16 else None
     y32 = empty((M, C), F32, x) if want_f32 else None
     mean, rstd = empty((M,), F32, x), empty((M,), F32, x)
-    _lib.call("ocn_layernorm_fwd", _chk(x, F32, "x"), _chk(w, F32, "w"), _chk(b, F32, "b"), _chk(y16, BF16, "y16"),
+    x16 = x.dtype == BF16
+    _lib.call("ocn_layernorm_fwd", _chk(x, BF16 if x16 else F32, "x"), int(x16), _chk(w, F32, "w"), _chk(b, F32, "b"), _chk(y16, BF16, "y16"),
               _chk(y32, F32, "y32"), _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), M, C, float(eps), _stream())
     return y16, y32, mean, rstd
 
@@ -152,14 +156,17 @@ def layernorm_fwd(x, w, b, want_bf16=True, want_f32=False, eps=1e-5):
 def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None, want_f32=True, want_bf16=False, dcol=None, deterministic=False):
     """(dx fp32 | None, dx bf16 | None); ``dres`` = the residual branch's fp32 gradient, added in; dw / db are accumulated into;
     ``dcol`` (fp32 [C], accumulated into): column sums of dx in fp32 = the bias gradient of the linear in front of this LayerNorm's input;
-    ``deterministic``: dw / db / dcol through per-workgroup slabs added in a fixed order instead of fp32 atomics"""
+    ``deterministic``: dw / db / dcol through per-workgroup slabs added in a fixed order instead of fp32 atomics.
+    ``x`` fp32 or bf16; with a bf16 ``x`` (image tower, bf16 residual stream) ``dy`` is bf16 and ``dres`` bf16 or fp32"""
     M, C = x.shape
     is32 = dy.dtype == F32
+    x16 = x.dtype == BF16
+    dr16 = dres is not None and dres.dtype == BF16
     dx32 = empty((M, C), F32, x) if want_f32 else None
     dx16 = empty((M, C), BF16, x) if want_bf16 else None
     ws = empty((_lib.load().ocn_layernorm_bwd_det_workspace_floats(M, C),), F32, x) if deterministic else None
-    _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, F32, "x"), _chk(w, F32, "w"),
-              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, F32, "dres"), _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"),
+    _lib.call("ocn_layernorm_bwd", _chk(dy, F32 if is32 else BF16, "dy"), int(is32), _chk(x, BF16 if x16 else F32, "x"), int(x16), _chk(w, F32, "w"),
+              _chk(mean, F32, "mean"), _chk(rstd, F32, "rstd"), _chk(dres, BF16 if dr16 else F32, "dres"), int(dr16), _chk(dx32, F32, "dx32"), _chk(dx16, BF16, "dx16"),
               _chk(dw, F32, "dw"), _chk(db, F32, "db"), _chk(dcol, F32, "dcol"), _chk(ws, F32, "det_workspace"), M, C, _stream())
     return dx32, dx16
 
@@ -393,9 +400,11 @@ def argmax_rows(text):
 
 
 def gather_rows(x, idx, B, L):
+    """fp32 [B, C] rows of ``x`` (fp32, or bf16: the image tower's bf16 residual stream)"""
     C = x.shape[1]
     out = empty((B, C), F32, x)
-    _lib.call("ocn_gather_rows", _chk(x, F32, "x"), _chk(idx, torch.int32, "idx"), _chk(out, F32, "out"), B, L, C, _stream())
+    x16 = x.dtype == BF16
+    _lib.call("ocn_gather_rows", _chk(x, BF16 if x16 else F32, "x"), int(x16), _chk(idx, torch.int32, "idx"), _chk(out, F32, "out"), B, L, C, _stream())
     return out
 
 
@@ -413,7 +422,7 @@ def scatter_rows(d, idx, dx, B, L, dx16=None):
 
 
 def scatter_add_rows(d, idx, dx, B, L, dx16=None):
-    """dx[row_b] += d[b]; dx16[row_b] = bf16(dx[row_b])"""
+    """dx[row_b] += d[b]; dx16[row_b] = bf16(dx[row_b]); ``dx`` None (bf16 gradient stream): dx16[row_b] = bf16(dx16[row_b] + d[b])"""
     C = d.shape[1]
     _lib.call("ocn_scatter_add_rows", _chk(d, F32, "d"), _chk(idx, torch.int32, "idx"), _chk(dx, F32, "dx"), _chk(dx16, BF16, "dx16"), B, L, C, _stream())
     return dx

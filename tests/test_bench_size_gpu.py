@@ -206,8 +206,15 @@ def test_vitb32_step_at_batch_512_against_cpu_oracle():
     assert pi <= 1e-5 and pt <= 1e-5 and pl <= 1e-5 and pg[0] <= 1e-4, (pi, pt, pl, pg)
 
 
-def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference():
-    """the WHOLE step at the bench's own batch (ViT-B-32, 4096 pairs: the launches bench.py times -- 204 800 image rows, the
+_BENCH_REF = {}  # fp32 reference + eager yardstick of the bench-batch step: computed once, shared by the three residual-stream modes
+
+
+@pytest.mark.parametrize("image_stream", ["fp32", "bf16", "bf16-fp32grad"])
+def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference(image_stream):
+    """Round 6: the same bound for every dtype of the image tower's residual stream -- fp32 (the stricter default), bf16 (what the reference's own
+    autocast runs: bench.py's headline configuration) and bf16 with an fp32 residual-gradient path.
+
+    VERDICT r3 #2: the WHOLE step at the bench's own batch (ViT-B-32, 4096 pairs: the launches bench.py times -- 204 800 image rows, the
     packed text rows, the persistent GEMMs' full tile walks and half-tile tails, 49 152-workgroup attention launches, the fused 4096 x 4096
     logits + cross-entropy) against the chunked fp32 GPU reference, which the previous test pins to the CPU oracle at batch 512: features, loss
     and ALL 302 gradients.
@@ -230,20 +237,23 @@ def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference():
     B = 4096
     state = init_state_dict(cfg, seed=0, perturb=True)
     batch = synthetic_batch(cfg, B, seed=1234)  # the bench's own batch
-    outs, grads = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=512)
-    outs = {k: v.cpu() for k, v in outs.items()}
-    grads = {k: v.cpu() for k, v in grads.items()}
-    torch.cuda.empty_cache()
-    a_outs, a_grads = torch_eager.amp_step_grads(cfg, state, batch["image"].cuda(), batch["text"].cuda())
-    amp_rel = {k: float((a_grads[k].cpu() - grads[k]).norm() / grads[k].norm().clamp_min(1e-30)) for k in grads}
-    amp_feat = max(float((a_outs[k].cpu() - outs[k]).abs().max()) for k in ("image_features", "text_features"))
-    del a_outs, a_grads
-    torch.cuda.empty_cache()
-    model = _build(cfg, state)
+    if "grads" not in _BENCH_REF:
+        outs, grads = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=512)
+        outs = {k: v.cpu() for k, v in outs.items()}
+        grads = {k: v.cpu() for k, v in grads.items()}
+        torch.cuda.empty_cache()
+        a_outs, a_grads = torch_eager.amp_step_grads(cfg, state, batch["image"].cuda(), batch["text"].cuda())
+        amp_rel = {k: float((a_grads[k].cpu() - grads[k]).norm() / grads[k].norm().clamp_min(1e-30)) for k in grads}
+        amp_feat = max(float((a_outs[k].cpu() - outs[k]).abs().max()) for k in ("image_features", "text_features"))
+        del a_outs, a_grads
+        torch.cuda.empty_cache()
+        _BENCH_REF.update(outs=outs, grads=grads, amp_rel=amp_rel, amp_feat=amp_feat)
+    outs, grads, amp_rel, amp_feat = _BENCH_REF["outs"], _BENCH_REF["grads"], _BENCH_REF["amp_rel"], _BENCH_REF["amp_feat"]
+    model = _build(cfg, state, image_stream=image_stream)
     out, loss = _step(model, batch)
     fi = float((out["image_features"].float().cpu() - outs["image_features"]).abs().max())
     ft = float((out["text_features"].float().cpu() - outs["text_features"]).abs().max())
-    _report(f"fp32-GPU-reference[ViT-B-32,B{B}]: feat max_abs {fi:.3e}/{ft:.3e} (eager amp_bf16: {amp_feat:.3e}) loss {float(loss):.6f} vs {float(outs['loss']):.6f}")
+    _report(f"fp32-GPU-reference[ViT-B-32,B{B},stream {image_stream}]: feat max_abs {fi:.3e}/{ft:.3e} (eager amp_bf16: {amp_feat:.3e}) loss {float(loss):.6f} vs {float(outs['loss']):.6f}")
     assert fi <= FEAT_TOL and ft <= FEAT_TOL
     assert abs(float(loss) - float(outs["loss"])) <= LOSS_TOL
     gmax = max(float(v.norm()) for v in grads.values())
@@ -255,11 +265,11 @@ def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference():
         worst.append((rel / tol, rel, k))
     worst.sort(reverse=True)
     for frac, rel, k in worst[:12]:
-        _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   grad rel_l2={rel:.3e} ({frac:.2f} of its bound; eager amp_bf16 {amp_rel[k]:.3e}) {k}")
+        _report(f"fp32-GPU-reference[ViT-B-32,B{B},stream {image_stream}]:   grad rel_l2={rel:.3e} ({frac:.2f} of its bound; eager amp_bf16 {amp_rel[k]:.3e}) {k}")
     med = lambda v: sorted(v)[len(v) // 2]
     nat_1d, nat_2d = [rel for _, rel, k in worst if grads[k].ndim <= 1], [rel for _, rel, k in worst if grads[k].ndim >= 2]
     amp_1d, amp_2d = [amp_rel[k] for k in grads if grads[k].ndim <= 1], [amp_rel[k] for k in grads if grads[k].ndim >= 2]
-    _report(f"fp32-GPU-reference[ViT-B-32,B{B}]:   1-D gradients: native median rel_l2 {med(nat_1d):.3e} worst {max(nat_1d):.3e}; eager amp_bf16 median {med(amp_1d):.3e} "
+    _report(f"fp32-GPU-reference[ViT-B-32,B{B},stream {image_stream}]:   1-D gradients: native median rel_l2 {med(nat_1d):.3e} worst {max(nat_1d):.3e}; eager amp_bf16 median {med(amp_1d):.3e} "
             f"worst {max(amp_1d):.3e}; matrices: native median {med(nat_2d):.3e} worst {max(nat_2d):.3e}; eager amp_bf16 median {med(amp_2d):.3e} worst {max(amp_2d):.3e}")
     assert len(worst) == 302 and worst[0][0] <= 1.0, worst[0]
     assert med(nat_1d) <= 1.1 * med(amp_1d) and med(nat_2d) <= 1.1 * med(amp_2d), "the native step is less accurate than eager PyTorch under the same amp_bf16 policy"

@@ -50,7 +50,7 @@ def test_library_loads_and_reports_errors(lib_path):
     with pytest.raises(RuntimeError, match="K=48 must be a multiple of 32"):
         _lib.call("ocn_gemm_nt", 0, 16, 48, 16, 48, 16, 64, 8, 64, 48, 0, 0, 0, 1.0, 0)
     with pytest.raises(RuntimeError, match="null operand"):
-        _lib.call("ocn_layernorm_fwd", 0, 0, 0, 0, 0, 0, 0, 4, 64, 1e-5, 0)
+        _lib.call("ocn_layernorm_fwd", 0, 0, 0, 0, 0, 0, 0, 0, 4, 64, 1e-5, 0)
 
 
 def test_library_contains_gfx950_code_object(lib_path):
