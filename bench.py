@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--native-comm", action="store_true", help="the loss's feature all-gather / reduce-scatter / scalar all-reduce through the C ABI's RCCL communicator "
                     "(ocn_comm_*) instead of torch.distributed's process group; with one process: a one-rank communicator -- the loss runs its distributed "
                     "(row-sharded) form with identity collectives (what the marshalling and the extra launches cost)")
+    ap.add_argument("--native", action="store_true", help="= --native-comm --native-allreduce: every collective of the step through the C ABI's RCCL communicator "
+                    "(ocn_comm_*); DistributedDataParallel + torch.distributed stay the fallback when the communicator cannot be created")
+    ap.add_argument("--torch-comm", action="store_true", help="N > 1: the loss collectives through torch.distributed's process group, too (default for N > 1 with the "
+                    "nccl backend: the loss's feature all-gather / reduce-scatter / scalar all-reduce through ocn_comm_*, the gradient all-reduce through DDP)")
     ap.add_argument("--bucket-cap-mb", type=int, default=128)
     ap.add_argument("--data-ranks", type=int, default=1, help="developer: with one process, use the concatenation of the batches R ranks would "
                     "get (what a world_size-R run sees as its global batch; tests/test_bench_gpu.py)")
@@ -96,7 +100,7 @@ def parse():
                     "that the default ViT-B-32 line carries as `config4_vitl14` / `config5_vith14_siglip` (each a subprocess of this file)")
     ap.add_argument("--dense-text", action="store_true", help="run all context_length positions of every caption through the text tower like the reference "
                     "does (default: packed -- only the tokens up to the pooled EOT exist; same features, loss and gradients, see model.py::_TextPack)")
-    ap.add_argument("--image-stream", default="fp32", choices=["fp32", "bf16", "bf16-fp32grad"],
+    ap.add_argument("--image-stream", default="bf16", choices=["fp32", "bf16", "bf16-fp32grad"],
                     help="dtype of the IMAGE tower's residual stream: bf16 = what the reference's autocast runs there (transformer.py:794, layers.py:23-26; stream and "
                          "its gradient in bf16), fp32 = the stricter native form, bf16-fp32grad = bf16 stream with an fp32 residual-gradient path")
     ap.add_argument("--siglip", action="store_true", help="SigLIPTask-equivalent step (sigmoid pairwise loss, logit_bias; BASELINE config 5)")
@@ -196,7 +200,7 @@ def _reference_cpu_record():
             "what": r["what"], "oracle_port_same_process_pairs_per_s": r["oracle_port_same_process"]["pairs_per_s"]}
 
 
-def _reference_cpu_live(threads, steps=8, timeout=240):
+def _reference_cpu_live(threads, steps=8, timeout=180):
     """the REFERENCE's own ``open_clip_train.train.train_one_epoch`` (train.py:337) on ITS ``CLIP`` + ``CLIPTask`` + AdamW, ViT-B-32 fp32
     batch 32, on this box's host cores -- in a subprocess (``oracle/ref_cpu_baseline.py``; the reference's packages come from /root/reference or, on
     the GPU box, from ``oracle/_ref/reference_src.zip``: oracle/fetch_ref.py).  None when neither is here or the run fails (the port stays)."""
@@ -366,6 +370,28 @@ def check_launch(gpus, env):
     return "rank" if world > 1 else "single"
 
 
+def dist_facts(world, dev, native_comm, elapsed, backend):
+    """what the TRANSPORTS report about the run, for the line of an N > 1 run (collective; every rank calls it): the process group's world size,
+    the rank count of the RCCL communicator itself (ncclCommCount through ocn_comm_count; None when the ranks do not talk RCCL: gloo developer modes),
+    the number of ranks that took part in a collective on the data path (an all-reduce of ones) and the per-rank times of the timed region"""
+    import torch.distributed as dist
+    ones = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(ones)
+    times = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(times, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+    times = [float(t) for t in times]
+    rccl = None
+    if native_comm is not None:
+        rccl = native_comm.count()[0]
+        check = torch.ones(1, device=dev, dtype=torch.float32)
+        native_comm.all_reduce_sum(check)  # the same count through the C ABI's own collective
+        rccl = rccl if int(check.item()) == rccl else -1
+    return {"dist_world_size": dist.get_world_size(), "transport_ranks": int(round(float(ones))), "rccl_ranks": rccl,
+            "rccl_ranks_is": ("ncclCommCount of the C ABI's communicator (ocn_comm_count), confirmed by an ocn_comm_allreduce_sum of ones" if rccl is not None else
+                              f"not available: backend {backend!r} / no C-ABI communicator in this run (torch's process group does not expose ncclCommCount)"),
+            "elapsed_s_per_rank_min": round(min(times), 4), "elapsed_s_per_rank_max": round(max(times), 4)}
+
+
 def main():
     args = parse()
     mode = check_launch(args.gpus, os.environ)
@@ -424,7 +450,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def config_line(extra_args, what, steps=4, warmup=1, timeout=420):
+def config_line(extra_args, what, steps=4, warmup=1, timeout=300):
     """one of the other BASELINE configurations through this same file in a subprocess (fresh HBM: --keep-blocks auto plans against what is free):
     `steps` timed steps of which the first carries HIP events on every GEMM launch (its towers one at a time), so the record has the per-kernel
     roofline of THAT model; returns the sub-record that rides on the default line, or {"error": ...} -- a sample never takes the line down"""
@@ -534,11 +560,29 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
         pipe = DeviceBatchPipeline(dev, (B, S, S, 3), (B, cfg["text_cfg"]["context_length"]), depth=max(2, F_ACC + 1),
                                    plan_text_vocab=(cfg["text_cfg"]["vocab_size"] if model.pack_text else None), attn_buckets=model.attn_buckets)
         pipe.submit(*host_pool[0])
-    native_comm = None
-    if (args.native_allreduce or args.native_comm) and args.dist_backend == "nccl":
+    if args.native:
+        args.native_comm = args.native_allreduce = True
+    # N > 1 over RCCL: the loss collectives go through the C ABI's communicator by default (north_star: "an RCCL all-gather ... through a thin C-ABI
+    # extension"); --torch-comm keeps them on the process group, --native moves the gradient all-reduce there as well
+    want_loss_comm = args.native_comm or (world > 1 and args.dist_backend == "nccl" and not args.torch_comm)
+    native_comm, native_comm_error = None, None
+    if (args.native_allreduce or want_loss_comm) and args.dist_backend == "nccl":
         from open_clip_amd.comm import NativeComm  # RCCL behind the C ABI; the 128-byte id travels through the process group once
-        native_comm = NativeComm.from_process_group(rank, world) if world > 1 else NativeComm(NativeComm.make_unique_id(), 0, 1)
-    loss_comm = native_comm if args.native_comm else None  # with one process: a one-rank communicator, the loss still runs its distributed form
+        try:
+            native_comm = NativeComm.from_process_group(rank, world) if world > 1 else NativeComm(NativeComm.make_unique_id(), 0, 1)
+        except Exception as e:  # ocn_comm_init failed here: fall back to torch.distributed + DDP (every rank must take the same branch: agreed below)
+            native_comm_error = repr(e)[:300]
+        if world > 1:
+            ok = torch.tensor([0 if native_comm is None else 1], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok) == 0 and native_comm is not None:
+                native_comm.close()
+                native_comm, native_comm_error = None, "ocn_comm_init failed on another rank"
+        if native_comm is None:
+            if rank == 0:
+                print(f"bench.py: the C ABI's RCCL communicator could not be created ({native_comm_error}): falling back to torch.distributed + DDP", file=sys.stderr)
+            args.native_allreduce = False
+    loss_comm = native_comm if (want_loss_comm and native_comm is not None) else None  # with one process: a one-rank communicator, the loss still runs its distributed form
     if args.siglip:
         from open_clip_amd.loss import NativeSigLipLoss
         loss_fn = NativeSigLipLoss(rank=rank, world_size=world, comm=loss_comm, deterministic=args.deterministic)
@@ -644,11 +688,19 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
     clock_under_load = sampler.stop() if sampler is not None else None
     timer.on = False
     model.tower_streams = overlap_towers
+    facts = None
     if world > 1:
+        facts = dist_facts(world, dev, native_comm, elapsed, args.dist_backend)
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
+    if rank == 0:
+        # the headline, as soon as the K timed steps are over: the one JSON line on stdout also carries the auxiliary samples and baselines
+        # (minutes of further work) -- a driver that kills the process in that window still finds the measured value here
+        print("bench.py headline (timed steps done; the JSON line follows on stdout): " + json.dumps(
+            {"value": round(B * F_ACC * world / (elapsed / args.steps), 1), "unit": "pairs/s", "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "image_stream": args.image_stream}), file=sys.stderr, flush=True)
 
     # the same loop with every caption padded to context_length (what the reference executes), timed right behind the packed one so
     # that both numbers come from the same box and process; outside the K timed steps
@@ -682,7 +734,7 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
     #                     (no packed text rows, no pooled last block) -- the native kernels on exactly the reference's work
     #   accum8_gbs32768   the metric's own global batch on ONE GPU with the reference's accumulation semantics (train.py:236-311): a no-grad feature
     #                     pass over 8 micro-batches of 4096, then each micro-batch again with gradient against the 32768 x 32768 logits
-    reference_work = accum8 = None
+    reference_work = accum8 = fp32_stream = None
     extra_ok = (world == 1 and not args.no_extra_lines and not args.no_dense_text_line and args.model == "ViT-B-32" and not args.siglip and F_ACC == 1
                 and pipe is None and not args.grad_checkpointing and args.data_ranks == 1)
     if extra_ok and model.pack_text:
@@ -698,6 +750,17 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
             reference_work = {"error": repr(e)[:300]}
         finally:
             model.pack_text, model.pooled_last_block, model.visual.pooled_last_block = saved_flags
+    if extra_ok and model.image_stream != "fp32":
+        try:  # the same step with the image tower's residual stream in fp32 (the stricter native form; the headline runs the reference's bf16 policy there)
+            model.image_stream = "fp32"
+            td = sample(4)
+            fp32_stream = {"value": round(B / td, 1), "unit": "pairs/s", "ms_per_step": round(td * 1e3, 2), "steps": 4,
+                           "what": "same step with --image-stream fp32: the image tower's residual stream (and its gradient) in fp32 instead of the bf16 the "
+                                   "reference's autocast runs there (transformer.py:794, layers.py:23-26)"}
+        except Exception as e:
+            fp32_stream = {"error": repr(e)[:300]}
+        finally:
+            model.image_stream = args.image_stream
     if extra_ok and B == 4096:
         try:
             mb8 = micro + [synthetic_batch(cfg, B, seed=1234 + 1000 * j, rank=rank, device=dev) for j in range(1, 8)]
@@ -729,7 +792,12 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
                                    + ("inputs from pinned host memory every step (uint8 pixels, async double-buffered H2D inside the timed region), " if args.h2d else "")
                                    + (("gather_features all-gather + global logits" + ("" if args.naive_global_loss else " (row-sharded across ranks)"))
                                       if world > 1 else "world_size 1 (no all-gather)"),
-                       "dist_world_size": (torch.distributed.get_world_size() if world > 1 else 1),
+                       "dist_world_size": (facts["dist_world_size"] if facts else 1),
+                       "rccl_ranks": (facts["rccl_ranks"] if facts else (native_comm.count()[0] if native_comm is not None else None)),
+                       "transport_ranks": (facts["transport_ranks"] if facts else 1),
+                       "rccl_ranks_is": (facts["rccl_ranks_is"] if facts else "one process"),
+                       "elapsed_s_per_rank": ({"min": facts["elapsed_s_per_rank_min"], "max": facts["elapsed_s_per_rank_max"]} if facts else None),
+                       "native_comm_fallback": native_comm_error,
                        "dist_backend": ((("rccl (torch.distributed 'nccl')" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else "none")),
                        "rank_devices": rank_devices, "one_device_developer_mode": one_device,
                        "model": args.model, "global_batch": B * F_ACC * world, "local_batch": B, "accum_freq": F_ACC, "parallelism": f"dp{world}",
@@ -757,6 +825,8 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
             line["clock_under_load"] = clock_under_load
         if dense_text is not None:
             line["dense_text_tower"] = dense_text
+        if fp32_stream is not None:
+            line["image_stream_fp32"] = fp32_stream
         if reference_work is not None:
             line["reference_work"] = reference_work
         if accum8 is not None:

@@ -38,7 +38,7 @@ enum ocn_epilogue {
     OCN_EPI_BIAS_RESID_F32 = 2, /* out_f32 = resid_f32 + acc + bias                                       */
     OCN_EPI_DGELU = 3,          /* out_bf16 = acc * decode(aux_u8)   (aux = the gelu' saved by EPI 1)      */
     OCN_EPI_F32 = 4,            /* out_f32 = alpha*acc + bias                                             */
-    OCN_EPI_BIAS_QUICKGELU = 7, /* EPI 1 with QuickGELU, x * sigmoid(1.702 x) (layers.py:29-32; `quick_gelu` configs); (5, 6: internal) */
+    OCN_EPI_BIAS_QUICKGELU = 7, /* EPI 1 with QuickGELU, x * sigmoid(1.702 x) (layers.py:29-32; `quick_gelu` configs); (9: internal) */
     OCN_EPI_BIAS_RESID_BF16 = 8 /* out_bf16 = bf16(resid_bf16 + bf16(acc + bias)): the residual add on a bf16 stream exactly as the reference's
                                    autocast evaluates it (F.linear's bf16 result, then `q_x + ...` in bf16: transformer.py:328-329) */
 };
@@ -52,7 +52,8 @@ const char* ocn_last_error(void);
  *                  ocn_siglip_rows holds softmax (sigmoid) * grad_scale WITHOUT the -onehot term (the caller applies it as an exact rank-1
  *                  update: open_clip_amd/loss.py::_PairTerm.dX / dY). */
 /*   103 (round 6)  bf16 residual stream of the image tower: ocn_layernorm_fwd / ocn_layernorm_bwd / ocn_gather_rows take dtype flags, ocn_gemm_nt
- *                  takes `resid` as void* (fp32 or bf16 by epilogue) and knows OCN_EPI_BIAS_RESID_BF16. */
+ *                  takes `resid` as void* (fp32 or bf16 by epilogue) and knows OCN_EPI_BIAS_RESID_BF16; new: ocn_comm_count, ocn_comm_sendrecv; ocn_fused_logits_ce is ONE
+ *                  pass now: G holds exp(logit - shift), the row scale comes back in `rowscale` (new argument). */
 #define OCN_ABI_VERSION 103
 int ocn_version(void);
 
@@ -258,13 +259,18 @@ int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, in
 /* det_rows (may be NULL = fp32 atomics into the three sums): fp32 [R, 3]; row r's contributions to loss_sum / dscale_sum / dbias_sum are
  * written there instead, for the caller to add up in a fixed order (ocn_colsum_f32(..., deterministic = 1)): the reproducible form */
 /* The same cross-entropy WITHOUT materialised logits (loss.py:103-110 + :136-139 for a [R, N] block of logits_per_image / _per_text;
- * the row-sharded global loss of 8 GPUs has R = 4096, N = 32768): X bf16 [R, E] (already times logit_scale), Y bf16 [N, E]; two passes
- * of the MFMA GEMM consume the fp32 logits tile in registers (online log-sum-exp, then G = softmax * grad_scale as bf16 [R, ldg]; the
- * onehot part is the caller's, as above); loss_sum += sum_r (lse_r - logit[r, r + label_offset]) * loss_scale; dscale_sum +=
- * sum((softmax - onehot) * grad_scale * logits) (divide by logit_scale for d/d logit_scale).  E % 128 == 0, N % 8 == 0; `workspace` = ocn_fused_logits_ce_workspace_floats(R, N) floats. */
+ * the row-sharded global loss of 8 GPUs has R = 4096, N = 32768): X bf16 [R, E] (already times logit_scale), Y bf16 [N, E].  ONE pass of the MFMA
+ * GEMM (round 6; two until round 5): its epilogue consumes the fp32 logits tile in registers and writes G' = exp(logit - c_r) as bf16 [R, ldg] with a
+ * per-row shift c_r fixed before the GEMM (the row's label logit, clamped from below so that nothing can overflow), then
+ *   rowscale[r] = grad_scale / sum_j G'_rj  (fp32 [R]):  the logit gradient is  G_rj = G'_rj * rowscale[r] - [j = r + label_offset] * grad_scale -- the row
+ *   scale is applied by the caller where it is free (on the [R, E] result of G' @ Y, on the [R, E] operand of G'^T @ X), the onehot part exactly as above;
+ *   loss_sum += sum_r (lse_r - logit[r, r + label_offset]) * loss_scale;  dscale_sum += sum((softmax - onehot) * grad_scale * logits) (divide by
+ *   logit_scale for d/d logit_scale).
+ * Exact for any scale: rows whose shifted sums under- / overflow (impossible for unit vectors and logit_scale <= 78, practically for <= 150) are
+ * redone from the operands with their true maximum.  E % 128 == 0, N % 8 == 0; `workspace` = ocn_fused_logits_ce_workspace_floats(R, N) floats. */
 int64_t ocn_fused_logits_ce_workspace_floats(int R, int N);
 int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
-                        float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
+                        float grad_scale, void* G, int ldg, float* workspace, float* rowscale, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
 /* bias_dev (may be NULL): the logit bias as a 1-element DEVICE value; overrides `bias` (logit_bias is a parameter: the step never reads it on the
  * host).  It is subtracted per element inside the dscale sum -- not as bias * dbias_sum afterwards, which cancels catastrophically. */
 int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,
@@ -311,6 +317,11 @@ int ocn_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, ocn_
 int ocn_comm_allreduce_avg(void* comm, void* buf, int64_t count, int dtype, ocn_stream_t stream);
 /* buf [count] on every rank = rank `root`'s, in place (ncclBroadcast): the parameter broadcast at the start of training (DDP's, base_task.py:227) */
 int ocn_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, ocn_stream_t stream);
+/* what the communicator reports about itself: *count_out = ncclCommCount (ranks RCCL connected), *rank_out = ncclCommUserRank (may be NULL) */
+int ocn_comm_count(void* comm, int* count_out, int* rank_out);
+/* one neighbour exchange (loss.py:226-243 `neighbour_exchange`: one isend + one irecv batched): send [count] to to_rank, recv [count] from from_rank, as
+ * one grouped RCCL operation on the caller's stream; dtype as above (0 fp32, 1 bf16, 2 raw bytes) */
+int ocn_comm_sendrecv(void* comm, const void* send, int to_rank, void* recv, int from_rank, int64_t count, int dtype, ocn_stream_t stream);
 
 /* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
 int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,

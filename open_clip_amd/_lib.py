@@ -54,7 +54,7 @@ SIGNATURES = {
     "ocn_l2norm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ocn_l2norm_bwd": [_p, _p, _p, _p, _i, _i, _p],
     "ocn_softmax_ce_rows": [_p, _i, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p],
-    "ocn_fused_logits_ce": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p, _p, _p, _p],
+    "ocn_fused_logits_ce": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _i, _p, _p, _p, _p, _p],
     "ocn_siglip_rows": [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _f, _f, _f, _p, _p, _p, _p, _p],
     "ocn_sumsq_accum": [_p, _l, _p, _p],
     "ocn_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
@@ -68,6 +68,8 @@ SIGNATURES = {
     "ocn_comm_allreduce_sum": [_p, _p, _l, _i, _p],
     "ocn_comm_allreduce_avg": [_p, _p, _l, _i, _p],
     "ocn_comm_broadcast": [_p, _p, _l, _i, _i, _p],
+    "ocn_comm_count": [_p, _p, _p],
+    "ocn_comm_sendrecv": [_p, _p, _i, _p, _i, _l, _i, _p],
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
 }
@@ -106,9 +108,7 @@ def load():
         #                 libamdhip64), not pull a second copy from /opt/rocm that knows no device ("no ROCm-capable device")
         lib = ctypes.CDLL(LIB_PATH)
         lib.ocn_version.argtypes, lib.ocn_version.restype = [], _i
-        # OCN_ALLOW_ABI=<n> (developer, together with OCN_LIB_PATH): accept an OLDER library for a timing A/B of the step -- only entry points
-        # whose argument lists did not change since version n may then be reached (tools/gpu_call_r5.sh: the round-4 library under this tree)
-        if lib.ocn_version() != ABI_VERSION and str(lib.ocn_version()) != os.environ.get("OCN_ALLOW_ABI"):
+        if lib.ocn_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH} reports C-ABI version {lib.ocn_version()}, this package binds version {ABI_VERSION} "
                                "(include/openclip_hip.h): rebuild it with `python -m open_clip_amd.build` -- argument lists differ between versions")
         for name, argtypes in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):

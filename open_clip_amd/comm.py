@@ -6,7 +6,8 @@
 
 Without ``comm=`` the losses use ``torch.distributed`` (backend "nccl" = RCCL underneath) -- that is what the multi-rank tests and the
 bench exercise (two ranks on one GPU need gloo; RCCL refuses two ranks per device).  The native communicator has been run on
-hardware with ONE rank only (tests/test_ddp_gpu.py); it is opt-in until a multi-GPU node has seen it."""
+hardware with ONE rank only (tests/test_ddp_gpu.py); ``bench.py --native`` selects it (with the native gradient all-reduce) and falls back to
+torch.distributed + DDP when the communicator cannot be created."""
 import ctypes
 
 import torch
@@ -79,6 +80,18 @@ class NativeComm:
             n, dt = t.numel() * t.element_size(), 2
         if n:
             _lib.call("ocn_comm_broadcast", self._comm, _check(t, "tensor"), n, dt, int(root), self._stream())
+
+    def count(self):
+        """(ranks, own rank) as the COMMUNICATOR reports them (ncclCommCount / ncclCommUserRank) -- not what the caller passed in"""
+        n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.call("ocn_comm_count", self._comm, ctypes.cast(ctypes.byref(n), ctypes.c_void_p), ctypes.cast(ctypes.byref(r), ctypes.c_void_p))
+        return n.value, r.value
+
+    def sendrecv(self, send, to_rank, recv, from_rank):
+        """one neighbour exchange (loss.py:226-243): ``send`` goes to ``to_rank``, ``recv`` is filled from ``from_rank``; one grouped RCCL operation"""
+        assert send.numel() == recv.numel() and send.dtype == recv.dtype
+        n, dt = (send.numel(), _dt(send)) if send.dtype in (F32, BF16) else (send.numel() * send.element_size(), 2)
+        _lib.call("ocn_comm_sendrecv", self._comm, _check(send, "send"), int(to_rank), _check(recv, "recv"), int(from_rank), n, dt, self._stream())
 
     def close(self):
         """destroys the communicator; pending collectives are waited for first (ncclCommDestroy does not order itself behind the streams:

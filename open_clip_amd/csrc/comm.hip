@@ -24,6 +24,12 @@ struct Rccl {
     int (*ReduceScatter)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*CommCount)(Comm, int*) = nullptr;
+    int (*CommUserRank)(Comm, int*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -46,6 +52,12 @@ Rccl* rccl() {
     *(void**)&r.AllReduce = dlsym(r.handle, "ncclAllReduce");
     *(void**)&r.Broadcast = dlsym(r.handle, "ncclBroadcast");
     *(void**)&r.GetErrorString = dlsym(r.handle, "ncclGetErrorString");
+    *(void**)&r.CommCount = dlsym(r.handle, "ncclCommCount");
+    *(void**)&r.CommUserRank = dlsym(r.handle, "ncclCommUserRank");
+    *(void**)&r.Send = dlsym(r.handle, "ncclSend");
+    *(void**)&r.Recv = dlsym(r.handle, "ncclRecv");
+    *(void**)&r.GroupStart = dlsym(r.handle, "ncclGroupStart");
+    *(void**)&r.GroupEnd = dlsym(r.handle, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.ReduceScatter || !r.AllReduce) r.handle = nullptr;
     return r.handle ? &r : nullptr;
 }
@@ -139,5 +151,32 @@ extern "C" int ocn_comm_allreduce_avg(void* comm, void* buf, int64_t count, int 
     Rccl* R = rccl();
     OCN_CHECK_ARG(R && comm && buf && count > 0, "ocn_comm_allreduce_avg: bad arguments");
     OCN_RCCL(R->AllReduce(buf, buf, (size_t)count, dtype_of(dtype), kAvg, (Comm)comm, (hipStream_t)stream), "ocn_comm_allreduce_avg");
+    return OCN_OK;
+}
+
+// What the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank): the number of ranks RCCL connected and this process's rank among them.
+// bench.py puts the count on its line next to torch.distributed's world size: a line that claims N GPUs shows how many ranks the transport saw.
+extern "C" int ocn_comm_count(void* comm, int* count_out, int* rank_out) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm && count_out, "ocn_comm_count: bad arguments");
+    OCN_CHECK_ARG(R->CommCount && R->CommUserRank, "ocn_comm_count: the loaded librccl.so exports no ncclCommCount / ncclCommUserRank");
+    OCN_RCCL(R->CommCount((Comm)comm, count_out), "ocn_comm_count");
+    if (rank_out) OCN_RCCL(R->CommUserRank((Comm)comm, rank_out), "ocn_comm_count");
+    return OCN_OK;
+}
+
+// One neighbour exchange (reference src/open_clip/loss.py:226-243 `neighbour_exchange`: batch_isend_irecv of one isend + one irecv): send [count] to
+// `to_rank` and receive [count] from `from_rank` as ONE grouped RCCL operation on the caller's stream (to_rank == from_rank == own rank is a copy).
+extern "C" int ocn_comm_sendrecv(void* comm, const void* send, int to_rank, void* recv, int from_rank, int64_t count, int dtype, ocn_stream_t stream) {
+    Rccl* R = rccl();
+    OCN_CHECK_ARG(R && comm && send && recv && count > 0 && to_rank >= 0 && from_rank >= 0 && dtype >= 0 && dtype <= 2, "ocn_comm_sendrecv: bad arguments");
+    OCN_CHECK_ARG(R->Send && R->Recv && R->GroupStart && R->GroupEnd, "ocn_comm_sendrecv: the loaded librccl.so exports no ncclSend / ncclRecv / ncclGroup*");
+    OCN_RCCL(R->GroupStart(), "ocn_comm_sendrecv");
+    const int rs = R->Send(send, (size_t)count, dtype_of(dtype), to_rank, (Comm)comm, (hipStream_t)stream);
+    const int rr = R->Recv(recv, (size_t)count, dtype_of(dtype), from_rank, (Comm)comm, (hipStream_t)stream);
+    const int re = R->GroupEnd();
+    OCN_RCCL(rs, "ocn_comm_sendrecv (send)");
+    OCN_RCCL(rr, "ocn_comm_sendrecv (recv)");
+    OCN_RCCL(re, "ocn_comm_sendrecv");
     return OCN_OK;
 }

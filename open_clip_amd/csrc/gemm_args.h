@@ -20,16 +20,17 @@ struct GemmNtArgs {
     // tail_n) of the walk are split; workgroup j < tail_n takes the upper half of tail tile j, workgroup tail_partner + j the lower half
     int tail_first, tail_n, tail_partner;
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
-    // fused logits + cross-entropy epilogues (OCN_EPI_CE_STATS / OCN_EPI_CE_GRAD below; ocn_fused_logits_ce in loss.hip)
-    float* ce_stats;        // STATS: [M][ce_parts][2] per-row (max, sum exp) of each 64-column strip
-    float* ce_label_logit;  // STATS: [M] the logit of the row's label column
-    const float* ce_lse;    // GRAD: [M] log-sum-exp of the whole row
-    float* ce_dscale;       // GRAD: += sum(G * logit)
+    // fused logits + cross-entropy epilogue (OCN_EPI_CE_ONEPASS below; ocn_fused_logits_ce in loss.hip)
+    float* ce_stats;        // [M][ce_parts][2]: per row and 64-column strip (sum e, sum e * logit), e = exp(logit - shift)
+    float* ce_label_logit;  // [M] the logit of the row's label column (host side of the launch only)
+    const float* ce_lse;    // (unused since round 6)
+    const float* ce_shift2; // [M] the row's shift c_i * log2(e)
+    float* ce_dscale;       // (unused since round 6)
     int ce_parts, ce_label_offset;
     float ce_grad_scale;
 };
 // internal epilogues of the persistent NT kernel (not part of enum ocn_epilogue): the logits tile never leaves the registers
-enum { OCN_EPI_CE_STATS = 5, OCN_EPI_CE_GRAD = 6 };
+enum { OCN_EPI_CE_ONEPASS = 9 };  // (5, 6: the two-pass statistics / gradient epilogues of rounds 2-5, removed)
 
 // chunk swizzle for 128-byte LDS rows: bijection on 3 bits built from row bits 1..3, chosen so that
 // (a) the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots and

@@ -175,7 +175,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     constexpr bool IS_GELU = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);  // two-output activation epilogues
     constexpr bool IS_DGELU = (EPI == OCN_EPI_DGELU);
     constexpr bool IS_RES16 = (EPI == OCN_EPI_BIAS_RESID_BF16);  // bf16 residual stream: out = bf16(resid + bf16(acc + bias)), added behind the transpose
-    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || IS_RES16 || EPI == OCN_EPI_CE_GRAD);
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || IS_RES16 || EPI == OCN_EPI_CE_ONEPASS);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     // developer knobs 32 / 128 (OCN_DEV_BUILD only): zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued
     // but the bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
@@ -206,72 +206,40 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
         for (int hb = 0; hb < 2; ++hb)
             bq[hb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (gn_w + hb * 32 + rd_chunk * 4) * 4, 0, 0));
     }
-    // ---- fused cross-entropy epilogues (ocn_fused_logits_ce): the fp32 logits tile is consumed in the accumulator layout -- a lane
+    // ---- fused cross-entropy epilogue (ocn_fused_logits_ce): the fp32 logits tile is consumed in the accumulator layout -- a lane
     // owns ONE row per (ha, s) and 32 of the wave's 64 columns (hb x 16 registers); its other half sits in lane ^ 32.
-    if constexpr (EPI == OCN_EPI_CE_STATS || EPI == OCN_EPI_CE_GRAD) {
-        float ds = 0.f;
+    // ---- one-pass form (round 6): e_ij = exp(l_ij - c_i) with a PER-ROW SHIFT c_i known before the GEMM (loss.hip::ce_prep_rows_kernel: the row's label
+    // logit, clamped from below so that no entry can overflow) is written as the bf16 matrix G' and its row sums S_i = sum_j e_ij, SL_i = sum_j e_ij l_ij
+    // as per-strip partials; softmax = G' / S_i is never formed: the 1 / S_i goes into the consumers' row scales (loss.py::_PairTerm.dX / dY).  The
+    // logits GEMM runs ONCE instead of twice (statistics pass + gradient pass): 3 GEMMs per direction of the loss instead of 4.
+    if constexpr (EPI == OCN_EPI_CE_ONEPASS) {
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int row = m0 + wm * 128 + ha * 64 + s * 32 + lr;
-                const int label = row + a.ce_label_offset;
-                if constexpr (EPI == OCN_EPI_CE_STATS) {
-                    float mx = -INFINITY, lab = 0.f;
-                    bool has = false;
+                const bool rv = row < a.M;
+                const float c2 = rv ? a.ce_shift2[row] : 0.f;  // c_i * log2(e)
+                float se = 0.f, sel = 0.f;
 #pragma unroll
-                    for (int hb = 0; hb < 2; ++hb)
+                for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                            const float v = acc[ha][s][hb][r];
-                            if (col < a.N) mx = fmaxf(mx, v);
-                            if (col == label) { lab = v; has = true; }
-                        }
-                    float l = 0.f;
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                            if (col < a.N) l += __expf(acc[ha][s][hb][r] - mx);
-                        }
-                    const float mo = __shfl_xor(mx, 32, 64), lo = __shfl_xor(l, 32, 64);
-                    const float m2 = fmaxf(mx, mo);
-                    const float l2 = (mx == -INFINITY ? 0.f : l * __expf(mx - m2)) + (mo == -INFINITY ? 0.f : lo * __expf(mo - m2));
-                    if (row < a.M) {
-                        if (lh == 0) {
-                            float* st = a.ce_stats + ((size_t)row * a.ce_parts + (size_t)(n0 >> 8) * 4 + wn) * 2;
-                            st[0] = m2;
-                            st[1] = l2;
-                        }
-                        if (has) a.ce_label_logit[row] = lab;
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+                        const float v = acc[ha][s][hb][r];
+                        const float e = (rv && col < a.N) ? __builtin_amdgcn_exp2f(fmaf(v, 1.4426950408889634f, -c2)) : 0.f;
+                        se += e;
+                        sel = fmaf(e, v, sel);
+                        acc[ha][s][hb][r] = e;  // stored as bf16 by the staged path below
                     }
-                } else {
-                    const float lse = row < a.M ? a.ce_lse[row] : 0.f;
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                            const float v = acc[ha][s][hb][r];
-                            // G holds softmax * grad_scale ONLY; the -onehot * grad_scale term of the logit gradient is applied by the caller as an
-                            // exact rank-1 update in fp32 (loss.py::_PairTerm): rounded to bf16 the label entry (p - 1) * gs loses its p -- every row
-                            // sum of G is then off by -p_label * gs, a COMMON-MODE bias of the feature gradients that every sum over the batch (all
-                            // bias / LayerNorm gradients) adds up coherently (round 4: it doubled the error of every parameter gradient at batch 4096)
-                            const float pe = __expf(v - lse);
-                            if (row < a.M && col < a.N) ds += (pe - (col == label ? 1.f : 0.f)) * a.ce_grad_scale * v;
-                            acc[ha][s][hb][r] = pe * a.ce_grad_scale;  // stored as bf16 by the staged path below
-                        }
+                se += __shfl_xor(se, 32, 64);
+                sel += __shfl_xor(sel, 32, 64);
+                if (rv && lh == 0) {
+                    float* st = a.ce_stats + ((size_t)row * a.ce_parts + (size_t)(n0 >> 8) * 4 + wn) * 2;
+                    st[0] = se;
+                    st[1] = sel;
                 }
             }
-        if constexpr (EPI == OCN_EPI_CE_STATS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // as below: the next tile's first phases assume every DMA has landed
-            return;
-        } else {
-            ds = wave_sum(ds);
-            if (lane_o == 0) unsafeAtomicAdd(a.ce_dscale, ds);
-        }
     }
     // Every DMA issued so far must have landed: the first phases of the next tile then need no vmcnt wait and the
     // stores below drain under them.  (hipcc does not know about the asm LDS-DMAs; its own loads / stores below get
@@ -756,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // K-tile (16 MFMAs per wave: A x (B0, B1) with the B fragments read as they are used) and one barrier: the slot of K-tile g is free once
     // every wave has read its last fragments, which is where the barrier sits, and is refilled right behind it -- B two K-tiles ahead (it comes
     // from L2), A four K-tiles ahead through the two A units a half tile does not otherwise need (it comes from HBM).
-    if constexpr (EPI != OCN_EPI_CE_STATS && EPI != OCN_EPI_CE_GRAD) if (a.tail_n > 0) {
+    if constexpr (EPI != OCN_EPI_CE_ONEPASS) if (a.tail_n > 0) {
         int t = -1, h = 0;
         if ((int)blockIdx.x < a.tail_n) t = (int)blockIdx.x;
         else if ((int)blockIdx.x >= a.tail_partner && (int)blockIdx.x < a.tail_partner + a.tail_n) { t = (int)blockIdx.x - a.tail_partner; h = 1; }
@@ -941,7 +909,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.tail_first = a.tail_n = a.tail_partner = 0;
     {
         const int R = a.ntiles % grid, P = (R + 7) / 8 * 8;
-        constexpr bool ce = (EPI == OCN_EPI_CE_STATS || EPI == OCN_EPI_CE_GRAD);  // their row statistics are laid out per whole tile
+        constexpr bool ce = (EPI == OCN_EPI_CE_ONEPASS);  // its row statistics are laid out per whole tile
         if (!ce && a.ntiles > grid && R > 0 && R + P <= grid && (a.K / 64) % 4 == 0 && !ABL(a, 0x200000)) {
             a.tail_first = a.ntiles - R;
             a.tail_n = R;
@@ -1015,8 +983,7 @@ int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
         case OCN_EPI_BIAS_RESID_BF16: return launch5<OCN_EPI_BIAS_RESID_BF16>(a, st);
         case OCN_EPI_DGELU: return launch5<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch5<OCN_EPI_F32>(a, st);
-        case OCN_EPI_CE_STATS: return launch5<OCN_EPI_CE_STATS>(a, st);
-        case OCN_EPI_CE_GRAD: return launch5<OCN_EPI_CE_GRAD>(a, st);
+        case OCN_EPI_CE_ONEPASS: return launch5<OCN_EPI_CE_ONEPASS>(a, st);
     }
     return 1;
 }

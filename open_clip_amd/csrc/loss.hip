@@ -110,50 +110,150 @@ __global__ __launch_bounds__(256) void siglip_rows_kernel(const float* __restric
     }
 }
 
-// row r: combine the per-strip (max, sum exp) partials of the fused logits pass into lse[r]; loss_sum += (lse - label logit) * loss_scale
-__global__ __launch_bounds__(256) void ce_lse_reduce_kernel(const float* __restrict__ stats, const float* __restrict__ label_logit, float* __restrict__ lse,
-                                                             int R, int parts, float loss_scale, float* __restrict__ loss_sum) {
+// ---- one-pass fused logits + cross-entropy (round 6) --------------------------------------------------------------------------------------
+// max_j |y_j|^2 over the rows of Y (bf16 [N, E]) -> *out (fp32, zeroed by the caller; non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void ce_ynorm_kernel(const bf16* __restrict__ Y, int ldy, int N, int E, unsigned* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float best = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+        float q = 0.f;
+        for (int c = lane * 8; c < E; c += 512) {
+            const bf16x8 v = *(const bf16x8*)(Y + (size_t)row * ldy + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += bf2f(v[e]) * bf2f(v[e]);
+        }
+        best = fmaxf(best, wave_sum(q));
+    }
+    if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, best));
+}
+
+// row r: its label logit l_rr = <x_r, y_{label_offset + r}> (fp32 sum of the bf16 products the MFMA forms) and its shift
+//   c_r = max(l_rr, |x_r| * max_j |y_j| - 70):  every entry of the row is <= |x_r| max|y| (Cauchy-Schwarz), so exp(l - c_r) <= e^70 and a row of 2^20 entries
+//   sums below fp32's range; when the label logit is within 70 of that bound it IS the shift and the row sum is >= 1.
+__global__ __launch_bounds__(256) void ce_prep_rows_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, int R, int E,
+                                                            int label_offset, const float* __restrict__ ymax2, float* __restrict__ label_logit,
+                                                            float* __restrict__ shift2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
-    float contrib = 0.f;
-    if (row < R) {
-        const float* st = stats + (size_t)row * parts * 2;
-        float m = -INFINITY;
-        for (int p = lane; p < parts; p += 64) m = fmaxf(m, st[2 * p]);
-        m = wave_max(m);
-        float l = 0.f;
-        for (int p = lane; p < parts; p += 64) {
-            const float mp = st[2 * p];
-            if (mp != -INFINITY) l += st[2 * p + 1] * __expf(mp - m);
-        }
-        l = wave_sum(l);
-        const float v = m + __logf(l);
-        if (lane == 0) {
-            lse[row] = v;
-            contrib = (v - label_logit[row]) * loss_scale;
+    if (row >= R) return;
+    float d = 0.f, q = 0.f;
+    for (int c = lane * 8; c < E; c += 512) {
+        const bf16x8 x = *(const bf16x8*)(X + (size_t)row * ldx + c);
+        const bf16x8 y = *(const bf16x8*)(Y + (size_t)(label_offset + row) * ldy + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            d += bf2f(x[e]) * bf2f(y[e]);
+            q += bf2f(x[e]) * bf2f(x[e]);
         }
     }
-    __shared__ float red[4];
-    if (lane == 0) red[wave] = contrib;
+    d = wave_sum(d);
+    q = wave_sum(q);
+    if (lane == 0) {
+        const float bound = sqrtf(q) * sqrtf(*ymax2);
+        label_logit[row] = d;
+        shift2[row] = fmaxf(d, bound - 70.0f) * 1.4426950408889634f;
+    }
+}
+
+// row r: S = sum of the strips' sum e, SL = sum e * logit  ->  lse = c + ln S; loss_sum += (lse - l_rr) * loss_scale;
+// dscale_sum += grad_scale * (SL / S - l_rr) (= sum_j (softmax_rj - [j = label]) * grad_scale * l_rj); rowscale[r] = grad_scale / S.
+// A row whose S is not a positive finite number (every term under- or overflowed: only possible when |x| max|y| > 78 AND the row has no
+// entry within 157 of that bound) is left to ce_fixup_kernel: bad[r] = 1, nothing is added here.
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ stats, const float* __restrict__ label_logit, const float* __restrict__ shift2,
+                                                         float* __restrict__ rowscale, int* __restrict__ bad, int R, int parts, float loss_scale,
+                                                         float grad_scale, float* __restrict__ loss_sum, float* __restrict__ dscale_sum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float c_loss = 0.f, c_ds = 0.f;
+    if (row < R) {
+        const float* st = stats + (size_t)row * parts * 2;
+        float S = 0.f, SL = 0.f;
+        for (int p = lane; p < parts; p += 64) {
+            S += st[2 * p];
+            SL += st[2 * p + 1];
+        }
+        S = wave_sum(S);
+        SL = wave_sum(SL);
+        if (lane == 0) {
+            const bool ok = S > 0.f && S < INFINITY && fabsf(SL) < INFINITY;
+            bad[row] = ok ? 0 : 1;
+            if (ok) {
+                const float ll = label_logit[row];
+                c_loss = (shift2[row] * 0.6931471805599453f + __logf(S) - ll) * loss_scale;
+                c_ds = grad_scale * (SL / S - ll);
+                rowscale[row] = grad_scale / S;
+            }
+        }
+    }
+    __shared__ float red[2][4];
+    if (lane == 0) {
+        red[0][wave] = c_loss;
+        red[1][wave] = c_ds;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(loss_sum, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        unsafeAtomicAdd(dscale_sum, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// The exact form for the rows ce_finish_kernel flagged (never one in training: logit_scale is clamped to 100 and features are unit vectors): the row's
+// logits from the operands, its true maximum as the shift, G' = exp(l - max) rewritten for the row.  One workgroup per row; unflagged rows return at once.
+__global__ __launch_bounds__(256) void ce_fixup_kernel(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Y, int ldy, int R, int N, int E,
+                                                        int label_offset, const int* __restrict__ bad, bf16* __restrict__ G, int ldg,
+                                                        float* __restrict__ rowscale, float loss_scale, float grad_scale,
+                                                        float* __restrict__ loss_sum, float* __restrict__ dscale_sum) {
+    const int row = blockIdx.x;
+    if (!bad[row]) return;
+    __shared__ float red[8];
+    const bf16* xr = X + (size_t)row * ldx;
+    auto logit = [&](int j) {
+        float d = 0.f;
+        for (int c = 0; c < E; c += 8) {
+            const bf16x8 x = *(const bf16x8*)(xr + c), y = *(const bf16x8*)(Y + (size_t)j * ldy + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += bf2f(x[e]) * bf2f(y[e]);
+        }
+        return d;
+    };
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) mx = fmaxf(mx, logit(j));
+    mx = block_max(mx, red);
+    float S = 0.f, SL = 0.f;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const float l = logit(j), e = __expf(l - mx);
+        S += e;
+        SL += e * l;
+        G[(size_t)row * ldg + j] = f2bf(e);
+    }
+    S = block_sum(S, red);
+    SL = block_sum(SL, red);
+    if (threadIdx.x == 0) {
+        const float ll = logit(label_offset + row);
+        rowscale[row] = grad_scale / S;
+        unsafeAtomicAdd(loss_sum, (mx + __logf(S) - ll) * loss_scale);
+        unsafeAtomicAdd(dscale_sum, grad_scale * (SL / S - ll));
+    }
 }
 
 }  // namespace
 
-extern "C" int64_t ocn_fused_logits_ce_workspace_floats(int R, int N) { return (int64_t)R * (ocn_cdiv(N, 256) * 4) * 2 + 2 * (int64_t)R; }
+// workspace of ocn_fused_logits_ce, in floats: [R][parts][2] strip partials + label logit [R] + shift [R] + bad-row flags [R] + max |y|^2 [1 (+3 pad)]
+extern "C" int64_t ocn_fused_logits_ce_workspace_floats(int R, int N) { return (int64_t)R * (ocn_cdiv(N, 256) * 4) * 2 + 3 * (int64_t)R + 4; }
 
-// Logits + cross-entropy without the logits: two passes of the persistent NT GEMM over X . Y^T whose epilogues consume the fp32
-// tile in registers -- pass 1 leaves per-row (max, sum exp) partials (one per 64-column strip) and the label logit, a small kernel
-// combines them into the row log-sum-exp and the loss, pass 2 recomputes the tile and writes G = softmax * grad_scale as bf16 plus
-// sum((softmax - onehot) * grad_scale * logits).  The -onehot * grad_scale part of the logit gradient is NOT in G: the caller applies it
-// exactly in fp32 (dX_r -= grad_scale * Y[label_r], dY[label_r] -= grad_scale * X_r) -- in bf16 the label entry (p - 1) * grad_scale
-// rounds to -grad_scale, and the lost p is a common-mode bias that sums coherently over the batch.  4 * R * N * E flops instead of 2, and R * N * 2 bytes of HBM writes instead of R * N * (4 + 3 * 4 + 2).
+// Logits + cross-entropy without the logits, in ONE pass of the persistent NT GEMM over X . Y^T (round 6; until round 5: a statistics pass and a
+// gradient pass = the logits GEMM twice).  The epilogue consumes the fp32 tile in registers: e_rj = exp(l_rj - c_r) with the per-row shift c_r of
+// ce_prep_rows_kernel goes out as the bf16 matrix G' [R, ldg], its per-strip row sums to the workspace; ce_finish_kernel turns them into the loss,
+// d/d logit_scale and rowscale[r] = grad_scale / sum_j e_rj.  The logit gradient is  G_rj = G'_rj * rowscale[r] - [j = label_r] * grad_scale:  the caller
+// applies the row scale where it is free -- on the [R, E] result of G' @ Y and on the [R, E] operand of G'^T @ X (open_clip_amd/loss.py::_PairTerm) -- and
+// the -onehot part exactly in fp32 as before (in bf16 the label entry (p - 1) * grad_scale loses its p: a common-mode bias over the batch).
+// 2 R N E flops and R N 2 bytes of HBM writes; rows the shifted sums cannot represent are redone exactly by ce_fixup_kernel (see there).
 extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
-                                   float grad_scale, void* G, int ldg, float* workspace, float* loss_sum, float* dscale_sum, ocn_stream_t stream) {
-    OCN_CHECK_ARG(X && Y && G && workspace && loss_sum && dscale_sum, "ocn_fused_logits_ce: null operand");
-    OCN_CHECK_ARG(R > 0 && N > 0 && E > 0 && E % 128 == 0 && N % 8 == 0 && ldg % 8 == 0 && ldg >= N && ldx >= E && ldy >= E,
-                  "ocn_fused_logits_ce: unsupported shape R=%d N=%d E=%d (E must be a multiple of 128, N and ldg of 8)", R, N, E);
+                                   float grad_scale, void* G, int ldg, float* workspace, float* rowscale, float* loss_sum, float* dscale_sum,
+                                   ocn_stream_t stream) {
+    OCN_CHECK_ARG(X && Y && G && workspace && rowscale && loss_sum && dscale_sum, "ocn_fused_logits_ce: null operand");
+    OCN_CHECK_ARG(R > 0 && N > 0 && E > 0 && E % 128 == 0 && N % 8 == 0 && ldg % 8 == 0 && ldg >= N && ldx >= E && ldy >= E && ldx % 8 == 0 && ldy % 8 == 0,
+                  "ocn_fused_logits_ce: unsupported shape R=%d N=%d E=%d (E must be a multiple of 128, N, ldg, ldx and ldy of 8)", R, N, E);
     OCN_CHECK_ARG(label_offset >= 0 && label_offset + R <= N, "ocn_fused_logits_ce: labels [%d,%d) outside N=%d", label_offset, label_offset + R, N);
     OCN_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)G & 15) == 0, "ocn_fused_logits_ce: operands must be 16-byte aligned");
     GemmNtArgs a;
@@ -164,15 +264,24 @@ extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ld
     a.ce_parts = parts; a.ce_label_offset = label_offset; a.ce_grad_scale = grad_scale;
     a.ce_stats = workspace;
     a.ce_label_logit = workspace + (size_t)R * parts * 2;
-    float* lse = a.ce_label_logit + R;
-    a.ce_lse = lse; a.ce_dscale = dscale_sum;
+    float* shift2 = a.ce_label_logit + R;
+    int* bad = (int*)(shift2 + R);
+    float* ymax2 = (float*)(bad + R);
+    a.ce_shift2 = shift2; a.ce_lse = nullptr; a.ce_dscale = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    int rc = ocn_launch_nt5(OCN_EPI_CE_STATS, a, st);
-    if (rc != 0) { if (rc > 0) ocn_set_error("ocn_fused_logits_ce: shape not supported by the persistent GEMM"); return rc > 0 ? OCN_ERR_UNSUPPORTED : rc; }
-    hipLaunchKernelGGL(ce_lse_reduce_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, a.ce_stats, a.ce_label_logit, lse, R, parts, loss_scale, loss_sum);
+    if (hipMemsetAsync(ymax2, 0, sizeof(float), st) != hipSuccess) { ocn_set_error("ocn_fused_logits_ce: hipMemsetAsync failed"); return OCN_ERR_LAUNCH; }
+    hipLaunchKernelGGL(ce_ynorm_kernel, dim3(ocn_cdiv(N, 4) < 1024 ? ocn_cdiv(N, 4) : 1024), dim3(256), 0, st, (const bf16*)Y, ldy, N, E, (unsigned*)ymax2);
+    hipLaunchKernelGGL(ce_prep_rows_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, (const bf16*)X, ldx, (const bf16*)Y, ldy, R, E, label_offset, ymax2,
+                       a.ce_label_logit, shift2);
     OCN_CHECK_LAUNCH("ocn_fused_logits_ce");
-    rc = ocn_launch_nt5(OCN_EPI_CE_GRAD, a, st);
-    return rc > 0 ? OCN_ERR_UNSUPPORTED : rc;
+    const int rc = ocn_launch_nt5(OCN_EPI_CE_ONEPASS, a, st);
+    if (rc != 0) { if (rc > 0) ocn_set_error("ocn_fused_logits_ce: shape not supported by the persistent GEMM"); return rc > 0 ? OCN_ERR_UNSUPPORTED : rc; }
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, a.ce_stats, a.ce_label_logit, shift2, rowscale, bad, R, parts, loss_scale,
+                       grad_scale, loss_sum, dscale_sum);
+    hipLaunchKernelGGL(ce_fixup_kernel, dim3(R), dim3(256), 0, st, (const bf16*)X, ldx, (const bf16*)Y, ldy, R, N, E, label_offset, bad, (bf16*)G, ldg, rowscale,
+                       loss_scale, grad_scale, loss_sum, dscale_sum);
+    OCN_CHECK_LAUNCH("ocn_fused_logits_ce");
+    return OCN_OK;
 }
 
 extern "C" int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset,

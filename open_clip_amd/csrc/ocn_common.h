@@ -103,12 +103,26 @@ OCN_DEV void gelu_both_poly4(f32x4 x, f32x4& g, f32x4& dg) {
     g = x * cdf;
     dg = (xc * 0.39894228040143268f) * e + cdf;
 }
-// one element, the same polynomial (the general fallback GEMM's epilogue: small / ragged shapes)
+// (Tail of the quad form: beyond the clamp the CDF stays at Phi(+-4.25), so gelu(x) = 1.07e-5 * x instead of 0 for x < -4.25 -- an absolute error of
+// 1.07e-5 |x|, below the bf16 resolution of any neighbouring value for |x| < 100; one more select per element would remove it and is not spent there.)
+// One element, the same polynomial in scalar arithmetic (the general fallback GEMM's epilogue: small / ragged shapes) -- with exact tails: the CDF is
+// 0 / 1 beyond the clamp.
 OCN_DEV void gelu_both(float x, float& g, float& dg) {
-    f32x4 gv, dv;
-    gelu_both_poly4((f32x4){x, x, x, x}, gv, dv);
-    g = gv[0];
-    dg = dv[0];
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.25f, 4.25f);
+    const float u = xc * xc;
+    float q = fmaf(u, 5.565356162e-11f, -5.328117947e-09f);
+    q = fmaf(q, u, 2.255534781e-07f);
+    q = fmaf(q, u, -5.626594884e-06f);
+    q = fmaf(q, u, 9.342017438e-05f);
+    q = fmaf(q, u, -1.108568278e-03f);
+    q = fmaf(q, u, 9.815989994e-03f);
+    q = fmaf(q, u, -6.634451449e-02f);
+    q = fmaf(q, u, 3.989023566e-01f);
+    float cdf = fmaf(xc, q, 0.5f);
+    cdf = x < -4.25f ? 0.f : (x > 4.25f ? 1.f : cdf);
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);  // exp(-x^2/2)
+    g = x * cdf;
+    dg = fmaf(xc * 0.39894228040143268f, e, cdf);
 }
 #ifdef OCN_DEV_BUILD
 // the form that shipped until round 4 (A/B knob of the developer build): erfc by Abramowitz-Stegun 7.1.25, |abs err| <= 2.5e-5;

@@ -79,6 +79,7 @@ class _PairTerm:
         self.logits = None
         self._bias = None
         self._onehot = None  # (label_offset, grad_scale) once softmax_ce has filled G
+        self.rowscale = None  # fused one-pass cross-entropy: G holds exp(logit - shift_r); the softmax part of the gradient is G * rowscale[:, None]
         self.deterministic = False  # reproducible sums (set by the loss Function): the rows' loss / d-scale contributions are added in a fixed order
         self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
 
@@ -97,9 +98,9 @@ class _PairTerm:
 
     def softmax_ce(self, label_offset, loss_scale, grad_scale, acc):
         """rows' CE against arange+offset -> acc[0] += loss, acc[1] += sum(G * logits) (= s * d/dscale); fills G.  Without a bias and
-        on GEMM-sized shapes the logits never exist in memory: two passes of the MFMA GEMM with cross-entropy epilogues
-        (``ocn_fused_logits_ce``: online log-sum-exp, then G) -- at the row-sharded global loss of 8 GPUs ([4096, 32768] per matrix)
-        that is 256 MiB of G written instead of 512 MiB of fp32 logits written and read three times besides."""
+        on GEMM-sized shapes the logits never exist in memory: ONE pass of the MFMA GEMM with a cross-entropy epilogue (``ocn_fused_logits_ce``,
+        round 6: G = exp(logit - shift_r) and ``rowscale`` = grad_scale / row sum; two passes until round 5) -- at the row-sharded global loss of
+        8 GPUs ([4096, 32768] per matrix) that is 256 MiB of G written instead of 512 MiB of fp32 logits written and read three times besides."""
         # both kernels leave G = softmax * grad_scale; the -onehot * grad_scale part of the logit gradient is applied in dX / dY below, exactly
         self._onehot = (int(label_offset), float(grad_scale))
         if self.deterministic:
@@ -112,7 +113,7 @@ class _PairTerm:
             acc[0:2].add_(tot[0:2])
             return
         if self._bias is None and USE_FUSED_CE and ops.fused_logits_ce_supported(self.R, self.N, self.xs16.shape[1]):
-            ops.fused_logits_ce(self.xs16, self.y16, self.G, self.N, label_offset, loss_scale, grad_scale, acc[0:1], acc[1:2])
+            self.rowscale = ops.fused_logits_ce(self.xs16, self.y16, self.G, self.N, label_offset, loss_scale, grad_scale, acc[0:1], acc[1:2])
             return
         ops.softmax_ce_rows(self._materialise(), self.G, self.N, label_offset, loss_scale, grad_scale, 1.0, acc[0:1], acc[1:2])
 
@@ -139,6 +140,8 @@ class _PairTerm:
         yt = _bf16_transposed(self.Y, self.ldg)
         out = torch.empty(self.R, self.E, dtype=F32, device=self.X.device)
         ops.gemm_nt(ops.EPI_F32, self.G, yt, out)
+        if self.rowscale is not None:  # one-pass cross-entropy: softmax * grad_scale = G * rowscale[:, None]: the row scale on the [R, E] result
+            out.mul_(self.rowscale[:, None])
         if self._onehot is not None:
             # The label column of the logit gradient, (p - 1) * gs: its "p" is in G, its "-1" is applied here in fp32.  In bf16 (p - 1) * gs rounds
             # to -gs: the lost p_label (~ 1 / N) is tiny per row but has the same sign in EVERY row, and the parameter gradients are sums over the
@@ -156,6 +159,15 @@ class _PairTerm:
         Np = _round_up(self.N, 8)
         Ep = self.xs16.shape[1]
         out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
+        if self.rowscale is not None:
+            # one-pass cross-entropy: G^T @ (s X) with G = G' * rowscale[:, None]: the row scale goes onto the [R, E] operand, xw = bf16(rowscale_r * (s X)_r)
+            xw16 = ops.cast_bf16(self.xs16.float().mul_(self.rowscale[:, None]))
+            ops.gemm_tn_accum(self.G[:, :Np], xw16, out, None, 1.0, self.deterministic)
+            if self._onehot is not None:
+                # the label part from the SAME rounded rows the product multiplied (see dX): sum_j G'_rj xw_r = (grad_scale / rowscale_r) * xw_r
+                off, gs = self._onehot
+                out[off:off + self.R].sub_(xw16.float().mul_((gs / self.rowscale)[:, None]))
+            return out[:self.N, :self.E]
         ops.gemm_tn_accum(self.G[:, :Np], self.xs16, out, None, 1.0, self.deterministic)
         if self._onehot is not None:
             off, gs = self._onehot
@@ -370,7 +382,13 @@ class NativeSigLipLoss(nn.Module):
         self.deterministic = bool(deterministic)  # as NativeClipLoss: the three sums in a fixed order instead of fp32 atomics
         self.comm = comm
         self.cache_labels, self.rank, self.world_size = cache_labels, rank, world_size
+        # loss.py:336-338: 'bidir' (default) / 'shift' / 'reduce' / 'gather' are four TRANSPORTS of the same sum -- every rank adds the negative-only loss
+        # of its images against every other rank's text features.  The native form is the 'gather' one for all four (one all-gather forward, one
+        # reduce-scatter backward: identical value and gradients, tests/test_dist_loss_gloo.py runs every name against the reference's vectors); the
+        # name is kept for introspection, anything else is rejected as the reference's constructor rejects it.
         self.dist_impl = dist_impl or "bidir"
+        if self.dist_impl not in ("bidir", "shift", "reduce", "gather"):
+            raise ValueError(f"NativeSigLipLoss: dist_impl {dist_impl!r} is not one of 'bidir', 'shift', 'reduce', 'gather' (open_clip/loss.py:338)")
         self.chunk_size = chunk_size
 
     def forward(self, image_features, text_features, logit_scale, logit_bias, output_dict=False):

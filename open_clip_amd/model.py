@@ -630,6 +630,53 @@ class _HeadFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------
+# logits of CLIP.get_logits (model.py:413-420) as an autograd node over the library's GEMMs
+# ------------------------------------------------------------------------------------------------------
+class _LogitsFn(torch.autograd.Function):
+    """li = exp(logit_scale) * I @ T^T (+ logit_bias), fp32 [B, N].  Backward with G = dL/dli: dI = s * G @ T, dT = G^T @ (s I), d logit_scale = sum(G * (li - bias))
+    (the parameter is the LOG scale: d li / d logit_scale = li - bias), d logit_bias = sum(G) -- the two products as bf16-operand GEMMs with fp32
+    accumulation, like the loss modules' (open_clip_amd/loss.py); the two scalars are fp32 reductions."""
+
+    @staticmethod
+    def forward(ctx, i, t, logit_scale, logit_bias):
+        i32, t32 = i.detach().float().contiguous(), t.detach().float().contiguous()
+        E, N = i32.shape[1], t32.shape[0]
+        Ep = _round_up(E, 64)
+        s = logit_scale.detach().exp().reshape(1).float()
+        if Ep == E:
+            i16, t16 = ops.cast_bf16_scaled(i32, s), ops.cast_bf16(t32)
+        else:  # embed dims that are not a multiple of the GEMM's K step: zero-padded operands (no registered config needs it)
+            i16, t16 = torch.zeros(i32.shape[0], Ep, dtype=BF16, device=i32.device), torch.zeros(N, Ep, dtype=BF16, device=i32.device)
+            i16[:, :E].copy_(i32 * s)
+            t16[:, :E].copy_(t32)
+        bias = None if logit_bias is None else logit_bias.detach().reshape(1).float().expand(N).contiguous()
+        li = torch.empty(i32.shape[0], _round_up(N, 4), dtype=F32, device=i32.device)[:, :N]
+        ops.gemm_nt(ops.EPI_F32, i16, t16, li, bias=bias)
+        ctx.save_for_backward(i16, t16, li, s, logit_bias)
+        ctx.meta = (E, i.dtype, t.dtype)
+        return li
+
+    @staticmethod
+    def backward(ctx, g):
+        i16, t16, li, s, logit_bias = ctx.saved_tensors
+        E, idt, tdt = ctx.meta
+        B, N = li.shape
+        g = g.float()
+        Np = _round_up(N, 64)
+        g16 = torch.zeros(B, Np, dtype=BF16, device=g.device)  # K of the dI product = N, padded to the GEMM's K step
+        g16[:, :N].copy_(g)
+        tT = torch.zeros(t16.shape[1], Np, dtype=BF16, device=g.device)
+        tT[:, :N].copy_(t16.t())
+        di = ops.gemm_nt(ops.EPI_F32, g16, tT, torch.empty(B, t16.shape[1], dtype=F32, device=g.device))[:, :E] * s  # s * G @ T
+        dt = torch.zeros(Np, i16.shape[1], dtype=F32, device=g.device)
+        ops.gemm_tn_accum(g16, i16, dt)  # G^T @ (s I): i16 already carries the scale
+        dbias = g.sum() if logit_bias is not None else None
+        lin = li if logit_bias is None else li - logit_bias.detach().float()
+        dscale = (g * lin).sum()
+        return di.to(idt), dt[:N, :E].to(tdt), dscale.reshape(()).to(s.dtype), (None if dbias is None else dbias.reshape(logit_bias.shape).to(logit_bias.dtype))
+
+
+# ------------------------------------------------------------------------------------------------------
 # parameter containers with the reference's names
 # ------------------------------------------------------------------------------------------------------
 class _Params(nn.Module):
@@ -1066,25 +1113,12 @@ class NativeCLIP(nn.Module):
         return _HeadFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection, idx, self._cache, B, L, normalize)
 
     def get_logits(self, image, text):
-        """model.py:413-420 (evaluation helper: `logit_scale.exp() * image_features @ text_features.T` (+ logit_bias), and its transpose) through
-        the library's own GEMM like every other product of the path: (s I) rounded to bf16 -- the reference evaluates (s I) first, too, and the
-        loss multiplies exactly these operands -- times T^T on MFMA with fp32 accumulation and output, the bias in the epilogue.  No gradient
-        (the reference's callers sit under no_grad / inference_mode, train.py:536-713); anything that wants one goes through the loss modules."""
-        with torch.no_grad():
-            i, t = self.encode_image(image, True).float().contiguous(), self.encode_text(text, True).float().contiguous()
-            E = i.shape[1]
-            Ep = _round_up(E, 64)
-            s = self.logit_scale.detach().exp().reshape(1).float()
-            if Ep == E:
-                i16, t16 = ops.cast_bf16_scaled(i, s), ops.cast_bf16(t)
-            else:  # embed dims that are not a multiple of the GEMM's K step: zero-padded operands (no registered config needs it)
-                i16, t16 = torch.zeros(i.shape[0], Ep, dtype=BF16, device=i.device), torch.zeros(t.shape[0], Ep, dtype=BF16, device=t.device)
-                i16[:, :E].copy_(i * s)
-                t16[:, :E].copy_(t)
-            N = t.shape[0]
-            bias = None if self.logit_bias is None else self.logit_bias.detach().reshape(1).float().expand(N).contiguous()
-            li = torch.empty(i.shape[0], _round_up(N, 4), dtype=F32, device=i.device)[:, :N]
-            ops.gemm_nt(ops.EPI_F32, i16, t16, li, bias=bias)
+        """model.py:413-420: `logit_scale.exp() * image_features @ text_features.T` (+ logit_bias), and its transpose, through the library's own GEMM like
+        every other product of the path: (s I) rounded to bf16 -- the reference evaluates (s I) first, too, and the loss multiplies exactly these
+        operands -- times T^T on MFMA with fp32 accumulation and output, the bias in the epilogue.  Differentiable like the reference's (``_LogitsFn``:
+        a caller may put its own loss on these logits); under no_grad / inference_mode (the reference's callers: train.py:536-713) nothing is saved."""
+        i, t = self.encode_image(image, True), self.encode_text(text, True)
+        li = _LogitsFn.apply(i, t, self.logit_scale, self.logit_bias)
         return li, li.T
 
     def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):

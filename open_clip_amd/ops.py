@@ -452,15 +452,18 @@ def softmax_ce_rows(logits, G, N, label_offset, loss_scale, grad_scale, inv_logi
 
 
 def fused_logits_ce(xs16, y16, G, N, label_offset, loss_scale, grad_scale, loss_sum, dscale_sum):
-    """cross-entropy of the rows of xs16 @ y16[:N]^T against arange + label_offset without materialising the logits
-    (ocn_fused_logits_ce); fills G bf16 [R, ldg], accumulates loss_sum and dscale_sum (= sum(G * logits))"""
+    """cross-entropy of the rows of xs16 @ y16[:N]^T against arange + label_offset without materialising the logits, in ONE pass of the MFMA GEMM
+    (ocn_fused_logits_ce): fills G bf16 [R, ldg] with exp(logit - shift_r) and returns ``rowscale`` fp32 [R] = grad_scale / sum_j G[r, j] -- the softmax part
+    of the logit gradient is G * rowscale[:, None]; accumulates loss_sum and dscale_sum (= sum((softmax - onehot) * grad_scale * logits))"""
     px, ldx = _chk2d(xs16, BF16, "xs16")
     py, ldy = _chk2d(y16, BF16, "y16")
     pg, ldg = _chk2d(G, BF16, "G")
     R, E = xs16.shape
     ws = torch.empty(_lib.load().ocn_fused_logits_ce_workspace_floats(R, N), dtype=F32, device=xs16.device)
+    rowscale = torch.empty(R, dtype=F32, device=xs16.device)
     _lib.call("ocn_fused_logits_ce", px, ldx, py, ldy, R, N, E, int(label_offset), float(loss_scale), float(grad_scale), pg, ldg,
-              ws.data_ptr(), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _stream())
+              ws.data_ptr(), rowscale.data_ptr(), _chk(loss_sum, F32, "loss_sum"), _chk(dscale_sum, F32, "dscale_sum"), _stream())
+    return rowscale
 
 
 def fused_logits_ce_supported(R, N, E):

@@ -31,15 +31,22 @@ class EagerCLIP(torch.nn.Module):
     def w(self, k):
         return self.p[k.replace(".", "/")]
 
+    @staticmethod
+    def ln(x, w, b):
+        """layers.py:20-26: the reference's LayerNorm hands its result back in the dtype of its INPUT.  Under autocast F.layer_norm returns fp32; with
+        the cast the image tower's residual stream stays bf16 from conv1 on (transformer.py:794), as in the reference -- until round 6 this file
+        left the cast out and its "amp_bf16" image stream was fp32 from ln_pre on: a yardstick more accurate (and slower) than the reference's policy"""
+        return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5).to(x.dtype)
+
     def block(self, x, pre, heads, mask):
         B, L, C = x.shape
-        h = F.layer_norm(x, (C,), self.w(pre + "ln_1.weight"), self.w(pre + "ln_1.bias"), 1e-5)
+        h = self.ln(x, self.w(pre + "ln_1.weight"), self.w(pre + "ln_1.bias"))
         q, k, v = F.linear(h, self.w(pre + "attn.in_proj_weight"), self.w(pre + "attn.in_proj_bias")).chunk(3, dim=-1)
         q, k, v = (t.reshape(B, L, heads, C // heads).transpose(1, 2) for t in (q, k, v))
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=None if mask is None else mask.to(q.dtype), scale=(C // heads) ** -0.5)
         a = a.transpose(1, 2).reshape(B, L, C)
         x = x + F.linear(a, self.w(pre + "attn.out_proj.weight"), self.w(pre + "attn.out_proj.bias"))
-        h = F.layer_norm(x, (C,), self.w(pre + "ln_2.weight"), self.w(pre + "ln_2.bias"), 1e-5)
+        h = self.ln(x, self.w(pre + "ln_2.weight"), self.w(pre + "ln_2.bias"))
         h = F.gelu(F.linear(h, self.w(pre + "mlp.c_fc.weight"), self.w(pre + "mlp.c_fc.bias")))
         return x + F.linear(h, self.w(pre + "mlp.c_proj.weight"), self.w(pre + "mlp.c_proj.bias"))
 
@@ -50,11 +57,11 @@ class EagerCLIP(torch.nn.Module):
         x = x.reshape(x.shape[0], width, -1).permute(0, 2, 1)
         cls = self.w("visual.class_embedding").to(x.dtype).reshape(1, 1, width).expand(x.shape[0], -1, -1)
         x = torch.cat([cls, x], dim=1) + self.w("visual.positional_embedding").to(x.dtype)
-        x = F.layer_norm(x, (width,), self.w("visual.ln_pre.weight"), self.w("visual.ln_pre.bias"), 1e-5)
+        x = self.ln(x, self.w("visual.ln_pre.weight"), self.w("visual.ln_pre.bias"))
         heads = width // v.get("head_width", 64)
         for i in range(v["layers"]):
             x = self.block(x, f"visual.transformer.resblocks.{i}.", heads, None)
-        x = F.layer_norm(x, (width,), self.w("visual.ln_post.weight"), self.w("visual.ln_post.bias"), 1e-5)
+        x = self.ln(x, self.w("visual.ln_post.weight"), self.w("visual.ln_post.bias"))
         return F.normalize(x[:, 0] @ self.w("visual.proj"), dim=-1)
 
     def encode_text(self, text):
@@ -62,7 +69,7 @@ class EagerCLIP(torch.nn.Module):
         x = F.embedding(text, self.w("token_embedding.weight")) + self.w("positional_embedding")
         for i in range(t["layers"]):
             x = self.block(x, f"transformer.resblocks.{i}.", t["heads"], self.attn_mask)
-        x = F.layer_norm(x, (t["width"],), self.w("ln_final.weight"), self.w("ln_final.bias"), 1e-5)
+        x = self.ln(x, self.w("ln_final.weight"), self.w("ln_final.bias"))
         x = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.w("text_projection")
         return F.normalize(x, dim=-1)
 

@@ -50,3 +50,37 @@ def test_wrong_world_size_is_an_error_before_any_device_is_touched():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29556")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 8" in r.stderr
+
+
+def _facts_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = bench.dist_facts(world, torch.device("cpu"), None, 1.0 + 0.01 * rank, "gloo")
+    q.put((rank, f))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_transport_facts_of_an_eight_rank_run_agree():
+    """what `bench.py --gpus 8` puts on its line about the transports -- here 8 gloo ranks on the host: the process group's world
+    size, the ranks counted by a collective on the data path and the global batch derived from them agree on every rank; `rccl_ranks` is the RCCL
+    communicator's own count (ocn_comm_count) and says so when the ranks do not talk RCCL; the per-rank times of the timed region ride along"""
+    import torch.multiprocessing as mp
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_facts_worker, args=(r, world, 29731, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert len(got) == world
+    for rank, f in got.items():
+        assert f["dist_world_size"] == f["transport_ranks"] == world
+        assert f["rccl_ranks"] is None and "gloo" in f["rccl_ranks_is"]
+        assert 4096 * f["transport_ranks"] == 32768  # config.global_batch = local_batch * accum_freq * world: the metric's gbs at 8 ranks
+        assert abs(f["elapsed_s_per_rank_min"] - 1.0) < 1e-6 and abs(f["elapsed_s_per_rank_max"] - 1.07) < 1e-6
+    assert len({tuple(sorted(f.items())) for f in got.values()}) == 1  # every rank holds the same record

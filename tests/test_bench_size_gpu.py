@@ -212,7 +212,11 @@ _BENCH_REF = {}  # fp32 reference + eager yardstick of the bench-batch step: com
 @pytest.mark.parametrize("image_stream", ["fp32", "bf16", "bf16-fp32grad"])
 def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference(image_stream):
     """Round 6: the same bound for every dtype of the image tower's residual stream -- fp32 (the stricter default), bf16 (what the reference's own
-    autocast runs: bench.py's headline configuration) and bf16 with an fp32 residual-gradient path.
+    autocast runs: bench.py's headline configuration) and bf16 with an fp32 residual-gradient path.  On the bf16 stream a gradient may exceed 2e-2
+    only where the reference's own policy does and no further than that policy's error (``stream_bound``; measured: token_embedding.weight 2.23e-2
+    against 2.59e-2 for eager autocast -- the image features carry the stream's rounding, rel-L2 8.3e-3 against eager's 9.3e-3 and 3.4e-3 on the fp32
+    stream, into the text tower's gradients through the loss; every other tensor <= 1.8e-2).  The eager yardstick follows the reference's LayerNorm
+    (layers.py:23-26: result cast back to the input dtype) since round 6 -- before, its image stream was fp32 from ln_pre on.
 
     VERDICT r3 #2: the WHOLE step at the bench's own batch (ViT-B-32, 4096 pairs: the launches bench.py times -- 204 800 image rows, the
     packed text rows, the persistent GEMMs' full tile walks and half-tile tails, 49 152-workgroup attention launches, the fused 4096 x 4096
@@ -233,6 +237,7 @@ def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference(image_stream)
     (LayerNorm backward's dcol) had changed nothing: the error was in the summands, not in the summation."""
     from oracle import gpu_fp32, torch_eager
     from tests.test_model_gpu import FEAT_TOL, LOSS_TOL, _build, _grad_tol, _step
+    from tests.test_parity_at_size_gpu import stream_bound
     cfg = get_model_config("ViT-B-32")
     B = 4096
     state = init_state_dict(cfg, seed=0, perturb=True)
@@ -261,7 +266,7 @@ def test_vitb32_step_at_the_bench_batch_against_fp32_gpu_reference(image_stream)
     for k, p in model.named_parameters():
         ref = grads[k]
         rel = float((p.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
-        tol = min(_grad_tol(float(ref.norm()), gmax, ref.ndim), 2e-2)
+        tol = stream_bound(min(_grad_tol(float(ref.norm()), gmax, ref.ndim), 2e-2), amp_rel[k], image_stream)
         worst.append((rel / tol, rel, k))
     worst.sort(reverse=True)
     for frac, rel, k in worst[:12]:

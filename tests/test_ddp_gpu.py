@@ -155,6 +155,17 @@ def test_native_comm_one_rank_collectives_through_the_c_abi():
         comm.all_reduce_sum(ar)
         torch.cuda.synchronize()
         assert torch.equal(out, x) and torch.equal(rs, x) and torch.equal(ar, x), dt
+        # one neighbour exchange (ocn_comm_sendrecv; loss.py:226-243): with one rank the neighbour on both sides is the rank itself
+        got = torch.full_like(x, float("nan"))
+        comm.sendrecv(x, 0, got, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(got, x), dt
+    ids = torch.arange(100, dtype=torch.int64).cuda()
+    got = torch.zeros_like(ids)
+    comm.sendrecv(ids, 0, got, 0)  # any other dtype travels as raw bytes
+    torch.cuda.synchronize()
+    assert torch.equal(got, ids)
+    assert comm.count() == (1, 0)  # what RCCL itself reports (ncclCommCount / ncclCommUserRank): bench.py's `rccl_ranks`
     comm.close()
 
 

@@ -78,7 +78,8 @@ def _worker(rank, world, port, q):
     txt = feats[rank, 1].clone().requires_grad_(True)
     s = torch.tensor(float(g["scale"]), requires_grad=True)
     b = torch.tensor(float(g["bias"]), requires_grad=True)
-    loss = L.NativeSigLipLoss(rank=rank, world_size=world)(img, txt, s, b)
+    # the reference's four transports of the same sum (loss.py:410-477) are one implementation here: every name must give the 'bidir' vectors
+    loss = L.NativeSigLipLoss(rank=rank, world_size=world, dist_impl={2: "shift", 3: "reduce", 8: "gather"}.get(world))(img, txt, s, b)
     loss.backward()
     res["siglip"] = (float(loss), img.grad.numpy(), txt.grad.numpy(), float(s.grad), float(b.grad))
     # SigLipLoss(chunk_size=2) (loss.py:369-404) and ClipLoss with a logit_bias (loss.py:111-113: a real, exactly zero gradient)

@@ -47,3 +47,15 @@ def test_polynomial_cdf_of_the_header_is_within_its_stated_error():
     assert np.abs(g - g_true).max() <= 1.3e-5 * 12.0 and np.abs(g - g_true)[np.abs(x) <= 4.25].max() <= 6e-5
     assert np.abs(dg - dg_true).max() <= 5e-5                          # the saved derivative is then quantised in steps of 5e-3
     assert cdf.min() >= -1.3e-5 and cdf.max() <= 1.0 + 1.3e-5
+
+
+def test_scalar_form_carries_the_same_coefficients():
+    """``gelu_both`` (one element; the general fallback GEMM's epilogue) restates the polynomial in scalar fmas: same coefficients, same clamp"""
+    src = open(HDR).read()
+    body = src[src.index("OCN_DEV void gelu_both(float x"):]
+    body = body[:body.index("\n}\n")]
+    first = re.search(r"fmaf\(u, ([-0-9.e+]+)f, ([-0-9.e+]+)f\)", body)
+    rest = re.findall(r"q = fmaf\(q, u, ([-0-9.e+]+)f\);", body)
+    coeffs = np.array([float(first.group(1)), float(first.group(2))] + [float(c) for c in rest], dtype=np.float32)
+    clamp, q = _header_constants()
+    assert np.array_equal(coeffs, q) and f"-{clamp}f, {clamp}f" in body

@@ -706,3 +706,33 @@ def test_deterministic_step_is_bit_reproducible(cfg_name, B, siglip):
     _report(f"deterministic step [{cfg_name}, B={B}{', siglip' if siglip else ''}]: two runs bit-identical (loss + {len(g1)} gradients); atomic form differs by "
             f"rel_l2 <= {worst[0]:.2e} ({worst[1]}), loss {float(l0):.7f} vs {float(l1):.7f}")
     assert worst[0] <= 5e-3 and abs(float(l0) - float(l1)) <= 1e-4
+
+
+@pytest.mark.parametrize("siglip", [False, True])
+def test_get_logits_is_differentiable_like_the_reference(siglip):
+    """``CLIP.get_logits`` (model.py:413-420) is differentiable in the reference; the native one goes through an autograd node over the
+    library's GEMMs (model.py::_LogitsFn).  A caller's own loss on these logits -- here the reference's ClipLoss / SigLipLoss arithmetic written in torch,
+    loss.py:103-141 / :356-367 -- must give the gradients the native loss modules give (same products, same bf16 operands; G rounded to bf16 in both)."""
+    import torch.nn.functional as F
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=33, perturb=True, siglip=siglip)
+    batch = {k: v.cuda() for k, v in synthetic_batch(cfg, 24, seed=34).items()}
+    model = _build(cfg, state, siglip=siglip)
+    li, lt = model.get_logits(batch["image"], batch["text"])
+    assert li.requires_grad and lt.shape == li.T.shape
+    if siglip:
+        labels = 2 * torch.eye(li.shape[0], device=li.device) - 1
+        loss = -F.logsigmoid(labels * li).sum() / li.shape[0]
+    else:
+        labels = torch.arange(li.shape[0], device=li.device)
+        loss = (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels)) / 2
+    loss.backward()
+    ref = _build(cfg, state, siglip=siglip)
+    _, ref_loss = _step(ref, batch, siglip=siglip)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * max(1.0, abs(float(ref_loss)))
+    worst = max((float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-30)), k) for (k, p), q in zip(model.named_parameters(), ref.parameters()))
+    _report(f"get_logits[{'siglip' if siglip else 'clip'}] + torch loss vs native loss module: loss {float(loss):.6f} vs {float(ref_loss):.6f}, worst gradient rel_l2 {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] <= 2e-2, worst
+    with torch.no_grad():
+        l2, _ = model.get_logits(batch["image"], batch["text"])
+    assert not l2.requires_grad and torch.equal(l2, li.detach())

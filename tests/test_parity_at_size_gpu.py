@@ -89,8 +89,18 @@ def test_loss_reference_is_pinned_to_the_cpu_oracle():
 
 
 # ---- whole steps ----------------------------------------------------------------------------------------------------------------------------
-def _whole_step_case(name, B, siglip, chunk, recompute, bound, tag, eager_whole_batch):
-    """native step vs chunked fp32 GPU reference; eager amp_bf16 (same operators under autocast) against the same reference as yardstick"""
+def stream_bound(tol, eager_rel, stream):
+    """tolerance of one gradient by the image tower's residual-stream dtype.  fp32 stream: ``tol``.  bf16 stream = the reference's own amp_bf16
+    policy there (layers.py:23-26; tests/test_reference_dropin.py::test_reference_stream_dtypes_under_autocast): a gradient may exceed ``tol`` only
+    where the reference's policy itself does (eager autocast against the same fp32 reference, ``eager_rel``) and no further than that policy's own
+    error -- never beyond 2 x tol.  Measured: ViT-B-32 at batch 4096 one tensor of 302 (token_embedding.weight 2.23e-2, policy 2.59e-2); ViT-L-14 at
+    batch 512 (24 image blocks: 48 roundings of the stream) up to 4.66e-2 against the policy's 4.93e-2, medians 3.0e-2 / 3.4e-2 against 3.5e-2 / 3.7e-2."""
+    return tol if stream == "fp32" else max(tol, min(2.0 * tol, eager_rel))
+
+
+def _whole_step_case(name, B, siglip, chunk, recompute, bound, tag, eager_whole_batch, streams=("fp32",)):
+    """native step vs chunked fp32 GPU reference; eager amp_bf16 (same operators under autocast) against the same reference as yardstick;
+    ``streams``: the residual-stream dtypes of the image tower to run against that one reference"""
     from oracle import gpu_fp32, torch_eager
     from tests.test_model_gpu import FEAT_TOL, LOSS_TOL, _build, _grad_tol, _step
     cfg = get_model_config(name)
@@ -108,7 +118,14 @@ def _whole_step_case(name, B, siglip, chunk, recompute, bound, tag, eager_whole_
     amp_feat = max(float((a_outs[k].float().cpu() - outs[k]).abs().max()) for k in ("image_features", "text_features"))
     del a_outs, a_grads
     torch.cuda.empty_cache()
-    model = _build(cfg, state, siglip=siglip)
+    for stream in streams:
+        _whole_step_check(cfg, state, batch, siglip, recompute, bound, f"{tag},stream {stream}" if len(streams) > 1 else tag, outs, grads, amp_rel, amp_feat, stream)
+        torch.cuda.empty_cache()
+
+
+def _whole_step_check(cfg, state, batch, siglip, recompute, bound, tag, outs, grads, amp_rel, amp_feat, stream):
+    from tests.test_model_gpu import FEAT_TOL, LOSS_TOL, _build, _grad_tol, _step
+    model = _build(cfg, state, siglip=siglip, image_stream=stream)
     if recompute:
         model.set_grad_checkpointing(True)  # every block recomputed, as the reference's --grad-checkpointing (transformer.py:577-585)
     out, loss = _step(model, batch, siglip=siglip)
@@ -139,6 +156,7 @@ def _whole_step_case(name, B, siglip, chunk, recompute, bound, tag, eager_whole_
         tol = min(tol, bound) if bound else tol
         if k == "logit_scale" and siglip:
             tol = max(tol, 2e-2 * scale_cond / max(abs(float(ref)), 1e-30))
+        tol = stream_bound(tol, amp_rel[k], stream)
         worst.append((rel / tol, rel, k))
     worst.sort(reverse=True)
     for frac, rel, k in worst[:10]:
@@ -163,13 +181,13 @@ def test_vitb32_siglip_step_at_the_bench_batch_against_fp32_gpu_reference():
 def test_vitl14_recompute_step_at_batch_512_against_fp32_gpu_reference():
     """4. BASELINE config 4's model and mode (ViT-L-14, every block recomputed, ClipLoss) at batch 512: 131 584 image rows through the 257-token
     attention kernels, patch 14 (K padded 588 -> 640), 24 + 12 blocks"""
-    _whole_step_case("ViT-L-14", 512, False, 64, True, None, "ViT-L-14 ckpt,B512", eager_whole_batch=False)
+    _whole_step_case("ViT-L-14", 512, False, 64, True, None, "ViT-L-14 ckpt,B512", eager_whole_batch=False, streams=("fp32", "bf16"))
 
 
 def test_vith14_siglip_recompute_step_at_batch_512_against_fp32_gpu_reference():
     """4. BASELINE config 5's model and mode (ViT-H-14 + SigLipLoss, every block recomputed) at batch 512: head_dim 80 streamed attention, width 1280,
     32 + 24 blocks, embed 1024"""
-    _whole_step_case("ViT-H-14", 512, True, 64, True, None, "ViT-H-14 SigLIP ckpt,B512", eager_whole_batch=False)
+    _whole_step_case("ViT-H-14", 512, True, 64, True, None, "ViT-H-14 SigLIP ckpt,B512", eager_whole_batch=False, streams=("fp32", "bf16"))
 
 
 # ---- 3. the loss's distributed branches at config-3 / config-5 size ----------------------------------------------------------------------------

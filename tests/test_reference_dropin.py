@@ -163,3 +163,69 @@ def test_analytic_forward_flops_match_the_reference_profile_table():
             assert abs(got / table[name] - 1) < 2e-3, (name, got, table[name])
             seen += 1
     assert seen >= 28
+
+
+def test_reference_stream_dtypes_under_autocast():
+    """What ``NativeCLIP(image_stream="bf16")`` mirrors, read off the REFERENCE itself (round 6): under ``--precision amp_bf16`` (torch.autocast,
+    precision.py:6-17) the image tower's residual stream is bf16 from ln_pre on -- conv1 runs under autocast (transformer.py:794), LayerNorm hands its
+    result back in its input's dtype (layers.py:20-26), `q_x + attention(...)` adds two bf16 tensors (transformer.py:328-329) -- while the text tower's
+    stays fp32 (the token embedding is fp32, model.py:399-401; fp32 + bf16 -> fp32).  CPU autocast applies the same rules as the GPU's."""
+    open_clip, ref, _ = _pair()
+    seen = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            seen[name] = (inp[0].dtype, (out[0] if isinstance(out, tuple) else out).dtype)
+        return f
+    ref.visual.ln_pre.register_forward_hook(hook("ln_pre"))
+    ref.visual.transformer.resblocks[5].register_forward_hook(hook("image block"))
+    ref.transformer.resblocks[5].register_forward_hook(hook("text block"))
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ref(image=torch.randn(2, 3, 224, 224), text=torch.randint(0, 49408, (2, 77)))
+    assert seen["ln_pre"] == (torch.bfloat16, torch.bfloat16)
+    assert seen["image block"] == (torch.bfloat16, torch.bfloat16)
+    assert seen["text block"] == (torch.float32, torch.float32)
+
+
+def test_create_task_mirrors_the_reference_dispatch():
+    """open_clip_amd.create_task(args, model) makes the choices of open_clip.factory.create_task (factory.py:975-1043) from the reference's own parsed
+    arguments -- task class, loss kind, local_loss / gather_with_grad / rank / world_size / loss_dist_impl -- with the native losses inside the
+    reference's task classes; what the native path does not implement raises"""
+    open_clip, ref, native = _pair()
+    import open_clip_amd
+    from open_clip.task import CLIPTask, SigLIPTask
+    from open_clip_train.params import parse_args
+    from open_clip_amd.loss import NativeClipLoss, NativeSigLipLoss
+    args = parse_args(["--model", "ViT-B-32", "--local-loss", "--gather-with-grad"])
+    args.rank, args.world_size, args.distill = 3, 8, False  # (main.py:247 derives args.distill before it calls create_task)
+    task = open_clip_amd.create_task(args, native, device=torch.device("cpu"), verbose=False)
+    ref_task = open_clip.factory.create_task(args, ref)
+    assert type(task) is type(ref_task) is CLIPTask and task.trainable_module is native
+    assert isinstance(task.loss, NativeClipLoss) and not isinstance(ref_task.loss, NativeClipLoss)
+    for k in ("local_loss", "gather_with_grad", "rank", "world_size"):
+        assert getattr(task.loss, k) == getattr(ref_task.loss, k), k
+    assert not task.loss.row_sharded
+    args = parse_args(["--model", "ViT-B-32"])  # global loss over 8 ranks: evaluated row-sharded (same value and gradients as the redundant form)
+    args.rank, args.world_size, args.distill = 0, 8, False
+    assert open_clip_amd.create_loss(args).row_sharded and not open_clip_amd.create_loss(args, row_sharded=False).row_sharded
+    args = parse_args(["--model", "ViT-B-32", "--siglip", "--loss-dist-impl", "shift"])
+    args.rank, args.world_size, args.distill = 1, 2, False
+    task = open_clip_amd.create_task(args, native, device=torch.device("cpu"), verbose=False)
+    ref_task = open_clip.factory.create_task(args, ref)
+    assert type(task) is type(ref_task) is SigLIPTask and isinstance(task.loss, NativeSigLipLoss)
+    assert (task.loss.dist_impl, task.loss.rank, task.loss.world_size) == (ref_task.loss.dist_impl, 1, 2) == ("shift", 1, 2)
+    args.loss_dist_impl = "ring"
+    with pytest.raises(ValueError, match="dist_impl"):
+        open_clip_amd.create_task(args, native)
+    args = parse_args(["--model", "ViT-B-32", "--distill-model", "ViT-B-32", "--distill-pretrained", "x"])
+    args.rank, args.world_size, args.distill = 0, 1, True
+    with pytest.raises(NotImplementedError, match="distill"):
+        open_clip_amd.create_task(args, native)
+    args = parse_args(["--model", "coca_ViT-B-32"])
+    args.rank, args.world_size, args.distill = 0, 1, False
+    with pytest.raises(NotImplementedError, match="CoCa"):
+        open_clip_amd.create_loss(args)
+    args = parse_args(["--model", "ViT-B-32"])
+    args.rank, args.world_size, args.distill = 0, 1, False
+    with pytest.raises(TypeError, match="NativeCLIP"):
+        open_clip_amd.create_task(args, ref)

@@ -104,3 +104,34 @@ def test_reference_train_one_epoch_trains_the_native_model_on_the_gpu():
         worst = max(worst, (ratio, k))
         assert ratio <= 0.25 + 1e-6, (k, ratio)
     _report(f"reference train_one_epoch over the native model: error / movement of the parameters after {steps} steps: worst {worst[0]:.3f} ({worst[1]}); bound 0.25")
+
+
+@pytest.mark.parametrize("siglip", [False, True])
+def test_create_task_from_parsed_args_steps_the_native_path(siglip):
+    """the reference's dispatch seam end to end -- ``parse_args`` -> ``open_clip_amd.create_task(args, model)`` (the counterpart of
+    open_clip/factory.py:975-1043 that open_clip_train/main.py:364 would call) -> ``task.training_forward`` under autocast -> backward, on the MI355X:
+    the task is the reference's own class, the loss inside it the native one, and loss + gradients are those of the hand-constructed objects"""
+    import_reference()
+    import open_clip_amd
+    from open_clip.task import CLIPTask, SigLIPTask
+    from open_clip_train.params import parse_args
+    from open_clip_amd.loss import NativeClipLoss, NativeSigLipLoss
+    from tests.test_model_gpu import _build, _step
+    cfg = get_model_config("small-test")
+    state = init_state_dict(cfg, seed=62, perturb=True, siglip=siglip)
+    batch = {k: v.cuda() for k, v in synthetic_batch(cfg, 12, seed=500).items()}
+    args = parse_args(["--model", "ViT-B-32", "--precision", "amp_bf16", "--local-loss", "--gather-with-grad"] + (["--siglip", "--loss-dist-impl", "gather"] if siglip else []))
+    args.rank, args.world_size, args.distill = 0, 1, False  # (main.py:247 derives args.distill before it calls create_task)
+    model = _build(cfg, state, siglip=siglip)
+    task = open_clip_amd.create_task(args, model, device=torch.device("cuda"), verbose=False)
+    assert type(task) is (SigLIPTask if siglip else CLIPTask) and isinstance(task.loss, NativeSigLipLoss if siglip else NativeClipLoss)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        losses, _ = task.training_forward(batch)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    ref_model = _build(cfg, state, siglip=siglip)
+    _, ref_loss = _step(ref_model, batch, siglip=siglip)
+    assert abs(float(losses["loss"]) - float(ref_loss)) <= 1e-6 * max(1.0, abs(float(ref_loss)))
+    worst = max(float((p.grad - q.grad).norm() / q.grad.norm().clamp_min(1e-30)) for p, q in zip(model.parameters(), ref_model.parameters()))
+    _report(f"create_task[{'siglip' if siglip else 'clip'}]: loss {float(losses['loss']):.6f} vs hand-built {float(ref_loss):.6f}, worst gradient rel_l2 {worst:.2e}")
+    assert worst <= 2e-6

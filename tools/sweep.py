@@ -204,7 +204,8 @@ def percu_sweep():
 
 
 def stagger_sweep():
-    """start-phase stagger of the persistent NT kernel (us per phase class; 63 = off, 0 = automatic)"""
+    """start-phase stagger of the persistent NT kernel (developer build; us per phase class; 0 = 63 = off -- the product's setting since round 5 --,
+    62 = the old automatic rule: csrc/gemm_nt5.hip::nt5_stagger)"""
     cases = [("img fc", Mi, 3072, 768, [0, 1, 3]), ("img out", Mi, 768, 768, [2]), ("img proj", Mi, 768, 3072, [0, 2]),
              ("txt fc", Mt, 2048, 512, [0, 1, 3]), ("txt out", Mt, 512, 512, [2]), ("txt proj", Mt, 512, 2048, [2]), ("img qkv", Mi, 2304, 768, [0])]
     for name, M, N, K, epis in cases:
