@@ -53,7 +53,8 @@ const char* ocn_last_error(void);
  *                  update: open_clip_amd/loss.py::_PairTerm.dX / dY). */
 /*   103 (round 6)  bf16 residual stream of the image tower: ocn_layernorm_fwd / ocn_layernorm_bwd / ocn_gather_rows take dtype flags, ocn_gemm_nt
  *                  takes `resid` as void* (fp32 or bf16 by epilogue) and knows OCN_EPI_BIAS_RESID_BF16; new: ocn_comm_count, ocn_comm_sendrecv; ocn_fused_logits_ce is ONE
- *                  pass now: G holds exp(logit - shift), the row scale comes back in `rowscale` (new argument). */
+ *                  pass now: G holds exp(logit - shift), the row scale comes back in `rowscale` (new argument); new: ocn_gemm_nt_splitk[_plan],
+ *                  ocn_scale_rows_bf16, ocn_sub_scaled_rows. */
 #define OCN_ABI_VERSION 103
 int ocn_version(void);
 
@@ -84,6 +85,17 @@ int ocn_gemm_tn_accum(const void* A, int lda, const void* B, int ldb, float* dW,
 int ocn_gemm_tn_accum2(const void* A1, int lda1, const void* B1, int ldb1, float* dW1, int ldw1, float* dbias1, int N1,
                        const void* A2, int lda2, const void* B2, int ldb2, float* dW2, int ldw2, float* dbias2, int N2,
                        int M, int K, float alpha, ocn_stream_t stream);
+
+/* Split-K form of ocn_gemm_nt for products with FEW output tiles and a LONG K (the loss's `G @ T` of loss.py:103-110's backward: [4096, 512] from
+ * K = 32768 has 32 tiles for 256 CUs): K is cut into `ksplit` slices, every slice of every 256 x 256 tile is a tile of the persistent kernel's walk and
+ * leaves its fp32 partial sum in slab s of `workspace` (ksplit * M * ldc floats); a second kernel forms
+ *   out[m, n] = scale * (rowscale[m] * sum_s ws[s][m][n] - sub_alpha * sub_rows[m][n])
+ * (rowscale fp32 [M], sub_rows bf16 [M, ld_sub], scale_dev a 1-element DEVICE value: each may be NULL) -- the row scale of the one-pass cross-entropy,
+ * the exact -onehot part of the logit gradient and logit_scale, which the caller would otherwise apply in four more passes over out.
+ * ocn_gemm_nt_splitk_plan: the ksplit that fills the chip (1 = no split: use ocn_gemm_nt).  K % (128 * ksplit) == 0. */
+int ocn_gemm_nt_splitk_plan(int M, int N, int K);
+int ocn_gemm_nt_splitk(const void* A, int lda, const void* B, int ldb, float* out, int ldc, int M, int N, int K, int ksplit, float* workspace,
+                       const float* rowscale, const void* sub_rows_bf16, int ld_sub, float sub_alpha, const float* scale_dev, ocn_stream_t stream);
 
 /* Run-to-run reproducible form of ocn_gemm_tn_accum (same arguments, same result up to fp32 summation ORDER, which here is fixed): no
  * two workgroups add into one address.  Shapes the hand-scheduled kernel takes (ocn_gemm_tn_det_workspace_bytes(M, N, K) > 0) need that
@@ -271,6 +283,10 @@ int ocn_softmax_ce_rows(const float* logits, int ld, void* G, int ldg, int R, in
 int64_t ocn_fused_logits_ce_workspace_floats(int R, int N);
 int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ldy, int R, int N, int E, int label_offset, float loss_scale,
                         float grad_scale, void* G, int ldg, float* workspace, float* rowscale, float* loss_sum, float* dscale_sum, ocn_stream_t stream);
+/* the caller's side of that row scale: out_bf16[r, :] = bf16(scale[r] * x_bf16[r, :]) (the [R, E] operand of G'^T @ X), and
+ * out_f32[r, :] -= (alpha / scale[r]) * x_bf16[r, :] (the label rows' -onehot part of that product, from the same rounded rows).  E % 8 == 0. */
+int ocn_scale_rows_bf16(const void* x_bf16, int ldx, const float* scale, void* out_bf16, int ldo, int R, int E, ocn_stream_t stream);
+int ocn_sub_scaled_rows(float* out, int ldo, const void* x_bf16, int ldx, const float* scale, float alpha, int R, int E, ocn_stream_t stream);
 /* bias_dev (may be NULL): the logit bias as a 1-element DEVICE value; overrides `bias` (logit_bias is a parameter: the step never reads it on the
  * host).  It is subtracted per element inside the dscale sum -- not as bias * dbias_sum afterwards, which cancels catastrophically. */
 int ocn_siglip_rows(const float* logits, int ld, void* G, int ldg, int R, int N, int label_offset, int negative_only,

@@ -19,6 +19,9 @@ SIGNATURES = {
     "ocn_gemm_tn_accum": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p],
     "ocn_gemm_tn_accum_det": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _f, _p, _l, _p],
     "ocn_gemm_tn_accum2": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p],
+    "ocn_gemm_nt_splitk": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p],
+    "ocn_scale_rows_bf16": [_p, _i, _p, _p, _i, _i, _i, _p],
+    "ocn_sub_scaled_rows": [_p, _i, _p, _i, _p, _f, _i, _i, _p],
     "ocn_cast_f32_bf16": [_p, _p, _l, _p],
     "ocn_cast_f32_bf16_scaled": [_p, _p, _l, _p, _p],
     "ocn_cast_transpose_f32_bf16": [_p, _p, _i, _i, _p],
@@ -83,7 +86,7 @@ DEBUG_SIGNATURES = {
     "ocn_debug_stream_with_cu_mask": [_p, _i, _p],
 }
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_det_workspace_bytes": ([_i, _i, _i], _l),
-            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l)}
+            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_gemm_nt_splitk_plan": ([_i, _i, _i], _i), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l)}
 
 ABI_VERSION = 103  # == OCN_ABI_VERSION of include/openclip_hip.h (tests/test_cabi.py compares the two): load() refuses any other library
 

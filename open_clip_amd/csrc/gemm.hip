@@ -457,7 +457,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (unsigned char*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0; a.ksplit = 1; a.ws_stride = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OCN_EPI_BF16: return launch_nt<OCN_EPI_BF16>(a, st);
@@ -470,6 +470,70 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     }
     ocn_set_error("ocn_gemm_nt: unknown epilogue %d", epilogue);
     return OCN_ERR_INVALID;
+}
+
+// ---- split-K NT GEMM: few output tiles, long K (the loss's G @ Y: [4096 x 512] from K = 32768 has 32 tiles for 256 CUs) -------------------------
+namespace {
+// out[m, n] = scale * (rowscale[m] * sum_s ws[s][m][n] - sub_alpha * sub[m][n]);  rowscale / sub / scale optional
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, long slab, int ksplit, float* __restrict__ out, int ldc, int M, int N,
+                                                             const float* __restrict__ rowscale, const bf16* __restrict__ sub, int ld_sub, float sub_alpha,
+                                                             const float* __restrict__ scale_dev) {
+    const int n4 = N / 4;
+    const long total = (long)M * n4;
+    const float sc = scale_dev ? *scale_dev : 1.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        const size_t o = (size_t)m * ldc + n;
+        f32x4 v = *(const f32x4*)(ws + o);
+        for (int s = 1; s < ksplit; ++s) v = v + *(const f32x4*)(ws + (size_t)s * slab + o);
+        if (rowscale) v = v * rowscale[m];
+        if (sub) {
+            const bf16x4 h = *(const bf16x4*)(sub + (size_t)m * ld_sub + n);
+            v = v - (f32x4){bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3])} * sub_alpha;
+        }
+        *(f32x4*)(out + o) = v * sc;
+    }
+}
+int g_splitk_cus = 0;
+}  // namespace
+
+// K-slices a [M, N] = A[M, K] . B[N, K]^T product should be cut into so that its 256 x 256 tiles fill the chip: 1 (= use ocn_gemm_nt) unless the
+// tiles cover at most half of the CUs and every slice keeps K >= 1024 (a multiple of 128)
+extern "C" int ocn_gemm_nt_splitk_plan(int M, int N, int K) {
+    if (g_splitk_cus == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_splitk_cus = n;
+    }
+    const int tiles = ocn_cdiv(M, 256) * ocn_cdiv(N, 256);
+    int ks = 1;
+    while (tiles * ks * 2 <= g_splitk_cus && K % (128 * ks * 2) == 0 && K / (ks * 2) >= 1024) ks *= 2;
+    return (M >= 1024 && N >= 192 && N % 8 == 0) ? ks : 1;
+}
+
+extern "C" int ocn_gemm_nt_splitk(const void* A, int lda, const void* B, int ldb, float* out, int ldc, int M, int N, int K, int ksplit, float* workspace,
+                                  const float* rowscale, const void* sub_rows_bf16, int ld_sub, float sub_alpha, const float* scale_dev, ocn_stream_t stream) {
+    OCN_CHECK_ARG(A && B && out && workspace, "ocn_gemm_nt_splitk: null operand");
+    OCN_CHECK_ARG(M > 0 && N > 0 && K > 0 && ksplit >= 2 && K % (128 * ksplit) == 0 && N % 8 == 0 && ldc % 8 == 0 && ldc >= N && lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0,
+                  "ocn_gemm_nt_splitk: unsupported shape M=%d N=%d K=%d ksplit=%d (K must be a multiple of 128 * ksplit; N, ldc, lda, ldb of 8)", M, N, K, ksplit);
+    OCN_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)workspace & 15) == 0, "ocn_gemm_nt_splitk: operands must be 16-byte aligned");
+    OCN_CHECK_ARG(!sub_rows_bf16 || (ld_sub >= N && ld_sub % 4 == 0), "ocn_gemm_nt_splitk: bad ld_sub");
+    GemmNtArgs a;
+    a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = workspace; a.bias = nullptr; a.resid = nullptr; a.aux = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = 1.0f;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0;
+    a.ksplit = ksplit; a.ws_stride = (long)M * ldc;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = ocn_launch_nt5(OCN_EPI_F32, a, st);
+    if (rc != 0) { if (rc > 0) ocn_set_error("ocn_gemm_nt_splitk: shape not supported by the persistent GEMM"); return rc > 0 ? OCN_ERR_UNSUPPORTED : rc; }
+    const long total = (long)M * (N / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, workspace, (long)M * ldc, ksplit, out, ldc, M, N, rowscale, (const bf16*)sub_rows_bf16, ld_sub,
+                       sub_alpha, scale_dev);
+    OCN_CHECK_LAUNCH("ocn_gemm_nt_splitk");
+    return OCN_OK;
 }
 
 extern "C" int ocn_set_gemm_variant(int nt_variant) {

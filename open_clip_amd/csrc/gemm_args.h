@@ -20,6 +20,10 @@ struct GemmNtArgs {
     // tail_n) of the walk are split; workgroup j < tail_n takes the upper half of tail tile j, workgroup tail_partner + j the lower half
     int tail_first, tail_n, tail_partner;
     int ablate;  // developer ablation mask (tools/gemm_bench.py)
+    // split-K (gemm_nt5.hip; ocn_gemm_nt_splitk): K in `ksplit` slices, slice s of every output tile is a tile of its own and writes its fp32 partial sum
+    // to out + s * ws_stride elements (out = the caller's workspace of ksplit slabs); 0 / 1 = off
+    int ksplit;
+    long ws_stride;
     // fused logits + cross-entropy epilogue (OCN_EPI_CE_ONEPASS below; ocn_fused_logits_ce in loss.hip)
     float* ce_stats;        // [M][ce_parts][2]: per row and 64-column strip (sum e, sum e * logit), e = exp(logit - shift)
     float* ce_label_logit;  // [M] the logit of the row's label column (host side of the launch only)

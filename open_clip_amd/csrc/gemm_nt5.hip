@@ -160,7 +160,8 @@ OCN_DEV void lds_r32x8(unsigned a0, unsigned (&q)[2][4]) {  // the lane's four 4
 
 template <int EPI, int AUX = 0>
 OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int n0, int wm, int wn, int lane, unsigned stg, u32x4 (&pf)[8],
-                       int ha_n, int row_shift, long long* dbg = nullptr) {
+                       int ha_n, int row_shift, long long* dbg = nullptr, int ks = 0) {
+    // ks: split-K launches (a.ksplit > 1, fp32 output only): this tile holds the partial sum of K-slice ks and goes to slab ks of the workspace a.out
     // ha_n / row_shift: 2 / 0 for a whole 256 x 256 tile; 1 / 0 or 64 for a HALF tile of the launch's last round (see the kernel): only acc[0]
     // holds results, for rows wm*128 + row_shift + 0..63
     // Lane constants are laundered through an empty asm once per tile: otherwise hipcc hoists ~40 VGPRs of epilogue
@@ -187,7 +188,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     const bool win = ABL(a, 0x80000) != 0;
     const unsigned omask = win ? 0xfff0u : ~0u;
     const long m_win = win ? (long)((blockIdx.x * 65536L) / ((long)a.ldc * (OUT_F32 ? 4 : 2))) : m0;
-    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc(a.out, m_win, m_st, a.ldc, OUT_F32 ? 4 : 2);
+    const __amdgpu_buffer_rsrc_t r_out = tile_rsrc((const char*)a.out + (size_t)ks * a.ws_stride * 4, m_win, m_st, a.ldc, OUT_F32 ? 4 : 2);
     const __amdgpu_buffer_rsrc_t r_aux = aux_is_out ? tile_rsrc(a.aux, m_win, m_st, a.ldc, 1) : tile_rsrc(a.aux, m0, m_ld, a.ldc, 1);  // gelu' in 8 bits
     const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(a.resid, m0, m_ld, a.ldc, IS_RES16 ? 2 : 4);
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
@@ -213,6 +214,8 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     // as per-strip partials; softmax = G' / S_i is never formed: the 1 / S_i goes into the consumers' row scales (loss.py::_PairTerm.dX / dY).  The
     // logits GEMM runs ONCE instead of twice (statistics pass + gradient pass): 3 GEMMs per direction of the loss instead of 4.
     if constexpr (EPI == OCN_EPI_CE_ONEPASS) {
+        // (measured and not adopted, round 6: an unmasked copy of this loop for interior tiles behind a uniform branch -- the second copy of the epilogue
+        // costs more registers than the two compares and selects per element it saves: 187 -> 333 us on [4096 x 32768 x 512])
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -416,7 +419,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int lr = lane & 31, lh = lane >> 5;
-    const int nk = a.K >> 6;  // K-tiles per output tile (even)
+    const int kc = a.K / a.ksplit;  // K of one tile: all of it, or one slice of a split-K launch (launch5: a multiple of 128)
+    const int nk = kc >> 6;   // K-tiles per output tile (even)
     const int G = gridDim.x;
     // a.tail_n > 0: the launch's last, partial round of tiles is split into HALF tiles (see below); the whole tiles are then exactly a.tail_first / G per
     // workgroup
@@ -456,20 +460,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // through once per band.  Row-major over all of N (band = tiles_n) re-reads the whole of B once per round of tiles when
     // B does not fit in L2 next to the A panels: measured 1.74 GB of L2-miss reads per launch instead of 0.32 GB on the
     // [204800 x 3072 x 768] GEMM (profiles/r01_pmc_hbm_traffic_before_band.txt).
-    const int tiles_m = a.ntiles / a.tiles_n;
+    // split-K (a.ksplit > 1): the walk has ksplit x as many entries; entry t = K-slice t / tiles_mn of output tile t % tiles_mn
+    const int tiles_mn = a.ntiles / a.ksplit;
+    const int tiles_m = tiles_mn / a.tiles_n;
     const int band_tiles = tiles_m * a.band;
-    auto tile_origin = [&](int i, int& m0, int& n0) {
-        const int tile = xcd_remap((int)blockIdx.x + i * G, a.ntiles);
+    auto tile_origin = [&](int i, int& m0, int& n0, int& ks) {
+        int tile = xcd_remap((int)blockIdx.x + i * G, a.ntiles);
+        ks = tile / tiles_mn;
+        tile -= ks * tiles_mn;
         const int cb = tile / band_tiles, r = tile - cb * band_tiles;
         const int width = min(a.band, a.tiles_n - cb * a.band);
         const int mi = r / width;
         m0 = mi * 256;
         n0 = (cb * a.band + (r - mi * width)) * 256;
     };
-    auto make_desc = [&](const bf16* base, int row0, int rows, int ld) -> u32x4 {
-        long bytes = (long)(rows - row0) * ld * 2;
+    auto make_desc = [&](const bf16* base, int row0, int rows, int ld, int kofs = 0) -> u32x4 {  // kofs: first column of the K-slice
+        long bytes = (long)(rows - row0) * ld * 2 - (long)kofs * 2;
         bytes = bytes > 0x7fffffffL ? 0x7fffffffL : bytes;
-        const unsigned long long p = (unsigned long long)(base + (size_t)row0 * ld);
+        const unsigned long long p = (unsigned long long)(base + (size_t)row0 * ld + kofs);
         u32x4 r;
         r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
         r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);
@@ -482,15 +490,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     unsigned ab_k = 0, a1_k = 0;                   // byte offset of the K-tile each cursor issues next (kt * 128)
     const unsigned k_end = (unsigned)nk * 128u;
     auto set_a1 = [&](int i) {
-        int m0, n0;
-        tile_origin(i, m0, n0);
-        dA1 = make_desc(a.A, m0, a.M, a.lda);
+        int m0, n0, ks;
+        tile_origin(i, m0, n0, ks);
+        dA1 = make_desc(a.A, m0, a.M, a.lda, ks * kc);
     };
     auto set_ab = [&](int i) {
-        int m0, n0;
-        tile_origin(i, m0, n0);
-        dA0 = make_desc(a.A, m0, a.M, a.lda);
-        dB = make_desc(a.B, n0, a.N, a.ldb);
+        int m0, n0, ks;
+        tile_origin(i, m0, n0, ks);
+        dA0 = make_desc(a.A, m0, a.M, a.lda, ks * kc);
+        dB = make_desc(a.B, n0, a.N, a.ldb, ks * kc);
     };
     const unsigned wave_dst = lds_base + wave * 2048;  // this wave's 2 x 1 KiB pieces inside a unit
     // one LDS-DMA piece: 64 lanes x 16 B from desc[voff + soff] to LDS m0 + lane*16 (m0 is compiler-reserved: save / restore)
@@ -547,8 +555,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         // 2: the workgroups of one tile ROW of the band in one class (A-panel sharers in step, rows spread over the four classes)
         if (a.stagger_mode == 1) phase = (int)blockIdx.x & 3;
         else if (a.stagger_mode == 2) {
-            int m0s, n0s;
-            tile_origin(0, m0s, n0s);
+            int m0s, n0s, kss;
+            tile_origin(0, m0s, n0s, kss);
             phase = (m0s >> 8) & 3;
         }
 #endif
@@ -697,8 +705,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         RD_A(fa[0], 0, 0, 0) RD_B(0, 0)
         LGKM0();
         SB();
-        int pm0, pn0;
-        tile_origin(i, pm0, pn0);
+        int pm0, pn0, pks;
+        tile_origin(i, pm0, pn0, pks);
         for (int kt = 0; kt + 2 < nk; kt += 2) {
             const bool skip = (kt == 0);
             KTILE(0, skip, false, 0)
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
             KTILE(1, false, true, 2)
         }
         STAMP(3)
-        epilogue5<EPI, AUX>(a, acc, pm0, pn0, wm, wn, lane, stg, pf, 2, 0, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr);
+        epilogue5<EPI, AUX>(a, acc, pm0, pn0, wm, wn, lane, stg, pf, 2, 0, (DBG && dbg && i < 8) ? dbg + i * 8 : nullptr, pks);
         if (ABL(a, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // developer knob: let the tile's stores drain before the next main loop
         if constexpr (PFN > 0) __builtin_amdgcn_s_barrier();  // publishes the next tile's first K-tile (see KTILE, PFM = 2)
         STAMP(4)
@@ -886,7 +894,8 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.ablate = 0;
 #endif
     a.tiles_n = ocn_cdiv(a.N, 256);
-    a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n;
+    if (a.ksplit < 1) a.ksplit = 1;
+    a.ntiles = ocn_cdiv(a.M, 256) * a.tiles_n * a.ksplit;  // split-K: every K-slice of every output tile is an entry of the walk
     a.band = nt5_band(a.M, a.N, a.K, (a.ablate >> 8) & 31);
     a.stagger = nt5_stagger<EPI>(a.ntiles, a.K, (a.ablate >> 13) & 63);
     a.first_wave = g_num_cu;
@@ -910,7 +919,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     {
         const int R = a.ntiles % grid, P = (R + 7) / 8 * 8;
         constexpr bool ce = (EPI == OCN_EPI_CE_ONEPASS);  // its row statistics are laid out per whole tile
-        if (!ce && a.ntiles > grid && R > 0 && R + P <= grid && (a.K / 64) % 4 == 0 && !ABL(a, 0x200000)) {
+        if (!ce && a.ksplit == 1 && a.ntiles > grid && R > 0 && R + P <= grid && (a.K / 64) % 4 == 0 && !ABL(a, 0x200000)) {
             a.tail_first = a.ntiles - R;
             a.tail_n = R;
             a.tail_partner = P;
@@ -973,6 +982,7 @@ extern "C" int ocn_debug_nt5_trace(long long* host_out /*[1024]*/) {
 int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
     // needs whole 128-k pairs of K-tiles, 16-byte aligned bf16 rows on the output side and vector-width columns
     if (a.K % 128 != 0 || a.N % 8 != 0 || a.ldc % 8 != 0) return 1;
+    if (a.ksplit > 1 && (epilogue != OCN_EPI_F32 || a.K % (128 * a.ksplit) != 0 || a.bias)) return 1;  // split-K: fp32 partial sums into the caller's slabs
     if (epilogue == OCN_EPI_DGELU && a.bias) return 1;  // the persistent kernel's dGELU epilogue carries no bias (no caller has one)
     if ((long)a.ldc * 4 * 256 >= 0x7fffffffL) return 1;  // 32-bit buffer offsets inside a tile
     switch (epilogue) {

@@ -387,11 +387,19 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     if (over > 1 && splits >= 1 && splits <= 10) splits *= over;
     if (splits < 1) splits = 1;
     if (splits > msteps) splits = msteps;
+    const long ldmax = a.lda > a.ldb ? a.lda : a.ldb;
     a.chunk = ocn_cdiv(msteps, splits) * 32;
+    // 32-bit buffer offsets inside an M-chunk (incl. the run-ahead past m_end): a chunk that would pass 2^31 bytes is cut further (round 6: the loss's
+    // G^T product at N = 32768 -- 32768 rows of 64 KiB -- used to fall back to the general kernel here, at half the speed)
+    while ((long)(a.chunk + 128) * ldmax * 2 >= 0x7fffffffL && splits < msteps && !a.ws) {
+        ++splits;
+        a.chunk = ocn_cdiv(msteps, splits) * 32;
+    }
     splits = ocn_cdiv(a.M, a.chunk);
     a.nwg = splits * ntile;
-    const long ldmax = a.lda > a.ldb ? a.lda : a.ldb;
-    if ((long)(a.chunk + 128) * ldmax * 2 >= 0x7fffffffL) return 1;  // 32-bit buffer offsets (incl. the run-ahead past m_end)
+    if ((long)(a.chunk + 128) * ldmax * 2 >= 0x7fffffffL) return 1;
+    // (measured and not adopted, round 6: a plain read-add-store epilogue for launches with ONE M-split, where no other workgroup adds into a tile --
+    // 159 -> 180 us on the loss's [32768 x 512] product: the dependent loads cost more than the uncontended atomics)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -111,20 +111,29 @@ __global__ __launch_bounds__(256) void siglip_rows_kernel(const float* __restric
 }
 
 // ---- one-pass fused logits + cross-entropy (round 6) --------------------------------------------------------------------------------------
-// max_j |y_j|^2 over the rows of Y (bf16 [N, E]) -> *out (fp32, zeroed by the caller; non-negative floats order like their bit patterns)
+// max_j |y_j|^2 over the rows of Y (bf16 [N, E]) -> *out (fp32, zeroed by the caller; non-negative floats order like their bit patterns): a wave per row,
+// two rows in flight, the workgroup's maximum through LDS and ONE atomic per workgroup (one per wave from 8192 workgroups serialised: 375 us at N = 32768)
 __global__ __launch_bounds__(256) void ce_ynorm_kernel(const bf16* __restrict__ Y, int ldy, int N, int E, unsigned* __restrict__ out) {
+    __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float best = 0.f;
-    for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
-        float q = 0.f;
+    const int stride = gridDim.x * 4;
+    for (int row = blockIdx.x * 4 + wave; row < N; row += 2 * stride) {
+        const int row2 = row + stride < N ? row + stride : row;
+        float q = 0.f, q2 = 0.f;
         for (int c = lane * 8; c < E; c += 512) {
-            const bf16x8 v = *(const bf16x8*)(Y + (size_t)row * ldy + c);
+            const bf16x8 v = *(const bf16x8*)(Y + (size_t)row * ldy + c), w = *(const bf16x8*)(Y + (size_t)row2 * ldy + c);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) q += bf2f(v[e]) * bf2f(v[e]);
+            for (int e = 0; e < 8; ++e) {
+                q += bf2f(v[e]) * bf2f(v[e]);
+                q2 += bf2f(w[e]) * bf2f(w[e]);
+            }
         }
-        best = fmaxf(best, wave_sum(q));
+        best = fmaxf(best, fmaxf(wave_sum(q), wave_sum(q2)));
     }
-    if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, best));
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 // row r: its label logit l_rr = <x_r, y_{label_offset + r}> (fp32 sum of the bf16 products the MFMA forms) and its shift
@@ -162,38 +171,48 @@ __global__ __launch_bounds__(256) void ce_prep_rows_kernel(const bf16* __restric
 __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ stats, const float* __restrict__ label_logit, const float* __restrict__ shift2,
                                                          float* __restrict__ rowscale, int* __restrict__ bad, int R, int parts, float loss_scale,
                                                          float grad_scale, float* __restrict__ loss_sum, float* __restrict__ dscale_sum) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    // 16 lanes per row: 16 rows per workgroup in flight (a wave per row left this kernel latency-bound: 32 us for 4096 rows of 512 partials)
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int row = blockIdx.x * 16 + grp;
     float c_loss = 0.f, c_ds = 0.f;
+    float S = 0.f, SL = 0.f;
     if (row < R) {
         const float* st = stats + (size_t)row * parts * 2;
-        float S = 0.f, SL = 0.f;
-        for (int p = lane; p < parts; p += 64) {
-            S += st[2 * p];
-            SL += st[2 * p + 1];
-        }
-        S = wave_sum(S);
-        SL = wave_sum(SL);
-        if (lane == 0) {
-            const bool ok = S > 0.f && S < INFINITY && fabsf(SL) < INFINITY;
-            bad[row] = ok ? 0 : 1;
-            if (ok) {
-                const float ll = label_logit[row];
-                c_loss = (shift2[row] * 0.6931471805599453f + __logf(S) - ll) * loss_scale;
-                c_ds = grad_scale * (SL / S - ll);
-                rowscale[row] = grad_scale / S;
-            }
+        for (int p = sub; p < parts; p += 16) {
+            const float2 v = *(const float2*)(st + 2 * p);
+            S += v.x;
+            SL += v.y;
         }
     }
-    __shared__ float red[2][4];
-    if (lane == 0) {
-        red[0][wave] = c_loss;
-        red[1][wave] = c_ds;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        S += __shfl_xor(S, o, 64);
+        SL += __shfl_xor(SL, o, 64);
+    }
+    if (row < R && sub == 0) {
+        const bool ok = S > 0.f && S < INFINITY && fabsf(SL) < INFINITY;
+        bad[row] = ok ? 0 : 1;
+        if (ok) {
+            const float ll = label_logit[row];
+            c_loss = (shift2[row] * 0.6931471805599453f + __logf(S) - ll) * loss_scale;
+            c_ds = grad_scale * (SL / S - ll);
+            rowscale[row] = grad_scale / S;
+        }
+    }
+    __shared__ float red[2][16];
+    if (sub == 0) {
+        red[0][grp] = c_loss;
+        red[1][grp] = c_ds;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(loss_sum, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        unsafeAtomicAdd(dscale_sum, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            a0 += red[0][i];
+            a1 += red[1][i];
+        }
+        unsafeAtomicAdd(loss_sum, a0);
+        unsafeAtomicAdd(dscale_sum, a1);
     }
 }
 
@@ -259,7 +278,7 @@ extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ld
     GemmNtArgs a;
     a.A = (const bf16*)X; a.B = (const bf16*)Y; a.out = G; a.bias = nullptr; a.resid = nullptr; a.aux = nullptr;
     a.lda = ldx; a.ldb = ldy; a.ldc = ldg; a.M = R; a.N = N; a.K = E; a.alpha = 1.0f;
-    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0; a.ksplit = 1; a.ws_stride = 0;
     const int parts = ocn_cdiv(N, 256) * 4;
     a.ce_parts = parts; a.ce_label_offset = label_offset; a.ce_grad_scale = grad_scale;
     a.ce_stats = workspace;
@@ -270,17 +289,66 @@ extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ld
     a.ce_shift2 = shift2; a.ce_lse = nullptr; a.ce_dscale = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ymax2, 0, sizeof(float), st) != hipSuccess) { ocn_set_error("ocn_fused_logits_ce: hipMemsetAsync failed"); return OCN_ERR_LAUNCH; }
-    hipLaunchKernelGGL(ce_ynorm_kernel, dim3(ocn_cdiv(N, 4) < 1024 ? ocn_cdiv(N, 4) : 1024), dim3(256), 0, st, (const bf16*)Y, ldy, N, E, (unsigned*)ymax2);
+    hipLaunchKernelGGL(ce_ynorm_kernel, dim3(ocn_cdiv(N, 8) < 512 ? ocn_cdiv(N, 8) : 512), dim3(256), 0, st, (const bf16*)Y, ldy, N, E, (unsigned*)ymax2);
     hipLaunchKernelGGL(ce_prep_rows_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, (const bf16*)X, ldx, (const bf16*)Y, ldy, R, E, label_offset, ymax2,
                        a.ce_label_logit, shift2);
     OCN_CHECK_LAUNCH("ocn_fused_logits_ce");
     const int rc = ocn_launch_nt5(OCN_EPI_CE_ONEPASS, a, st);
     if (rc != 0) { if (rc > 0) ocn_set_error("ocn_fused_logits_ce: shape not supported by the persistent GEMM"); return rc > 0 ? OCN_ERR_UNSUPPORTED : rc; }
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, a.ce_stats, a.ce_label_logit, shift2, rowscale, bad, R, parts, loss_scale,
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(ocn_cdiv(R, 16)), dim3(256), 0, st, a.ce_stats, a.ce_label_logit, shift2, rowscale, bad, R, parts, loss_scale,
                        grad_scale, loss_sum, dscale_sum);
     hipLaunchKernelGGL(ce_fixup_kernel, dim3(R), dim3(256), 0, st, (const bf16*)X, ldx, (const bf16*)Y, ldy, R, N, E, label_offset, bad, (bf16*)G, ldg, rowscale,
                        loss_scale, grad_scale, loss_sum, dscale_sum);
     OCN_CHECK_LAUNCH("ocn_fused_logits_ce");
+    return OCN_OK;
+}
+
+namespace {
+// out16[r, :] = bf16(scale[r] * x16[r, :])
+__global__ __launch_bounds__(256) void scale_rows_bf16_kernel(const bf16* __restrict__ x, int ldx, const float* __restrict__ scale, bf16* __restrict__ out, int ldo, int R, int E) {
+    const int e8 = E / 8;
+    const long total = (long)R * e8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / e8), c = (int)(i % e8) * 8;
+        const bf16x8 v = *(const bf16x8*)(x + (size_t)r * ldx + c);
+        const float sc = scale[r];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(v[e]) * sc);
+        *(bf16x8*)(out + (size_t)r * ldo + c) = o;
+    }
+}
+// out[r, :] -= (alpha / scale[r]) * x16[r, :]
+__global__ __launch_bounds__(256) void sub_scaled_rows_kernel(float* __restrict__ out, int ldo, const bf16* __restrict__ x, int ldx, const float* __restrict__ scale, float alpha, int R, int E) {
+    const int e4 = E / 4;
+    const long total = (long)R * e4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / e4), c = (int)(i % e4) * 4;
+        const bf16x4 v = *(const bf16x4*)(x + (size_t)r * ldx + c);
+        const float k = alpha / scale[r];
+        f32x4 o = *(f32x4*)(out + (size_t)r * ldo + c);
+        o = o - (f32x4){bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])} * k;
+        *(f32x4*)(out + (size_t)r * ldo + c) = o;
+    }
+}
+}  // namespace
+
+// The caller's side of the one-pass cross-entropy's row scale (see ocn_fused_logits_ce): out_bf16[r] = bf16(scale[r] * x_bf16[r]) -- the [R, E] operand of
+// G'^T @ X -- and out_f32[r] -= (alpha / scale[r]) * x_bf16[r] -- the label rows' -onehot part of that product, from the same rounded rows.  E % 8 == 0.
+extern "C" int ocn_scale_rows_bf16(const void* x, int ldx, const float* scale, void* out, int ldo, int R, int E, ocn_stream_t stream) {
+    OCN_CHECK_ARG(x && scale && out && R > 0 && E > 0 && E % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "ocn_scale_rows_bf16: bad arguments");
+    const long total = (long)R * (E / 8);
+    hipLaunchKernelGGL(scale_rows_bf16_kernel, dim3((int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, scale,
+                       (bf16*)out, ldo, R, E);
+    OCN_CHECK_LAUNCH("ocn_scale_rows_bf16");
+    return OCN_OK;
+}
+extern "C" int ocn_sub_scaled_rows(float* out, int ldo, const void* x, int ldx, const float* scale, float alpha, int R, int E, ocn_stream_t stream) {
+    OCN_CHECK_ARG(out && x && scale && R > 0 && E > 0 && E % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "ocn_sub_scaled_rows: bad arguments");
+    const long total = (long)R * (E / 4);
+    hipLaunchKernelGGL(sub_scaled_rows_kernel, dim3((int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, out, ldo, (const bf16*)x, ldx,
+                       scale, alpha, R, E);
+    OCN_CHECK_LAUNCH("ocn_sub_scaled_rows");
     return OCN_OK;
 }
 

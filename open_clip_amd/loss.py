@@ -81,7 +81,10 @@ class _PairTerm:
         self._onehot = None  # (label_offset, grad_scale) once softmax_ce has filled G
         self.rowscale = None  # fused one-pass cross-entropy: G holds exp(logit - shift_r); the softmax part of the gradient is G * rowscale[:, None]
         self.deterministic = False  # reproducible sums (set by the loss Function): the rows' loss / d-scale contributions are added in a fixed order
-        self.G = torch.zeros(self.R, self.ldg, dtype=BF16, device=X.device)
+        # the logit gradient's operand matrix: every column below N is written by the loss kernel; only the padding (K of the G @ Y product in steps of 64) must be zero
+        self.G = torch.empty(self.R, self.ldg, dtype=BF16, device=X.device)
+        if self.ldg > self.N:
+            self.G[:, self.N:].zero_()
 
     def compute_logits(self, bias=None):
         """``bias``: None or a 1-element device tensor (SigLIP's logit_bias), broadcast to the epilogue's bias vector.  The fp32
@@ -139,6 +142,13 @@ class _PairTerm:
         """s * G @ Y  -> [R, E] fp32"""
         yt = _bf16_transposed(self.Y, self.ldg)
         out = torch.empty(self.R, self.E, dtype=F32, device=self.X.device)
+        ks = ops.gemm_nt_splitk_plan(self.R, self.E, self.ldg) if self.E % 8 == 0 else 1
+        if ks > 1:
+            # few output tiles, long K (one rank's rows of the 8-GPU loss: [4096, 512] from K = 32768 is 32 tiles): K in slices that fill the chip; the
+            # row scale of the one-pass cross-entropy, the exact -onehot part (see below) and logit_scale ride in the slices' reduction
+            off, gs = self._onehot if self._onehot is not None else (0, 0.0)
+            sub = self.y16[off:off + self.R, :self.E] if self._onehot is not None else None
+            return ops.gemm_nt_splitk(self.G, yt, out, ks, rowscale=self.rowscale, sub_rows=sub, sub_alpha=gs, scale=self.s)
         ops.gemm_nt(ops.EPI_F32, self.G, yt, out)
         if self.rowscale is not None:  # one-pass cross-entropy: softmax * grad_scale = G * rowscale[:, None]: the row scale on the [R, E] result
             out.mul_(self.rowscale[:, None])
@@ -154,25 +164,35 @@ class _PairTerm:
             out.sub_(self.y16[off:off + self.R, :self.E].float(), alpha=gs)
         return out.mul_(self.s)
 
-    def dY(self):
-        """G^T @ (s X) -> [N, E] fp32"""
+    def dY(self, into=None):
+        """G^T @ (s X) -> [N, E] fp32.  ``into``: a zeroed fp32 [N, E] view (row stride free) to accumulate into instead of a fresh buffer -- the two
+        directions' results side by side in the [N, 2E] payload of the reduce-scatter, without a torch.cat of 2 x 64 MiB at N = 32768"""
         Np = _round_up(self.N, 8)
         Ep = self.xs16.shape[1]
-        out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
+        if into is not None and Np == self.N and Ep == self.E:
+            out = into
+        else:
+            out = torch.zeros(Np, Ep, dtype=F32, device=self.X.device)
         if self.rowscale is not None:
             # one-pass cross-entropy: G^T @ (s X) with G = G' * rowscale[:, None]: the row scale goes onto the [R, E] operand, xw = bf16(rowscale_r * (s X)_r)
-            xw16 = ops.cast_bf16(self.xs16.float().mul_(self.rowscale[:, None]))
+            xw16 = ops.scale_rows_bf16(self.xs16, self.rowscale)
             ops.gemm_tn_accum(self.G[:, :Np], xw16, out, None, 1.0, self.deterministic)
             if self._onehot is not None:
                 # the label part from the SAME rounded rows the product multiplied (see dX): sum_j G'_rj xw_r = (grad_scale / rowscale_r) * xw_r
                 off, gs = self._onehot
-                out[off:off + self.R].sub_(xw16.float().mul_((gs / self.rowscale)[:, None]))
-            return out[:self.N, :self.E]
+                ops.sub_scaled_rows(out[off:off + self.R], xw16, self.rowscale, gs)
+            return self._into(out, into)
         ops.gemm_tn_accum(self.G[:, :Np], self.xs16, out, None, 1.0, self.deterministic)
         if self._onehot is not None:
             off, gs = self._onehot
             out[off:off + self.R].sub_(self.xs16.float(), alpha=gs)  # xs16 = bf16(s X): the rows the G^T (s X) product multiplied
-        return out[:self.N, :self.E]
+        return self._into(out, into)
+
+    def _into(self, out, into):
+        if into is None or out is into:
+            return out[:self.N, :self.E]
+        into.copy_(out[:self.N, :self.E])
+        return into
 
 
 def _all_gather(out, inp, comm=None):
@@ -235,7 +255,9 @@ class _ClipLossFn(torch.autograd.Function):
             dI, dT = ti.dX(), tt.dX()            # through the local operands
             d_all = None
             if gather_with_grad:                  # ... and through the gathered ones (summed over ranks in backward)
-                d_all = torch.cat([tt.dY(), ti.dY()], dim=1).contiguous()  # [N, 2E]: d I_all | d T_all
+                d_all = torch.zeros(world_size * B, 2 * E, dtype=F32, device=dev)  # [N, 2E]: d I_all | d T_all, written in place
+                tt.dY(into=d_all[:, :E])
+                ti.dY(into=d_all[:, E:])
         elif row_sharded and not gather_with_grad:
             # Same loss and the same local gradients as the branch below (loss.py:106-107, :47-50), without its W-fold
             # redundancy: rank r evaluates only ITS rows of logits_per_image and logits_per_text
@@ -249,7 +271,9 @@ class _ClipLossFn(torch.autograd.Function):
             for term in (ti, tt):
                 term.softmax_ce(B * rank, 0.5 / N, 0.5 / N, acc)
             dI, dT = ti.dX(), tt.dX()
-            through_cols = torch.cat([tt.dY(), ti.dY()], dim=1).contiguous()  # [N, 2E]: d I_all | d T_all from my rows
+            through_cols = torch.zeros(N, 2 * E, dtype=F32, device=dev)  # [N, 2E]: d I_all | d T_all from my rows, written in place
+            tt.dY(into=through_cols[:, :E])
+            ti.dY(into=through_cols[:, E:])
             mine = torch.empty(B, 2 * E, dtype=F32, device=dev)
             _reduce_scatter_sum(mine, through_cols, comm)
             dI = dI + mine[:, :E]

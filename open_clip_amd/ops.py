@@ -66,6 +66,44 @@ def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
     return out
 
 
+def gemm_nt_splitk_plan(M, N, K):
+    """K-slices ``gemm_nt_splitk`` should use for out[M,N] = a[M,K] @ b[N,K]^T (1: the product fills the chip as it is -- use ``gemm_nt``)"""
+    return int(_lib.load().ocn_gemm_nt_splitk_plan(int(M), int(N), int(K)))
+
+
+def gemm_nt_splitk(a, b, out, ksplit, rowscale=None, sub_rows=None, sub_alpha=0.0, scale=None):
+    """out[M,N] fp32 = scale * (rowscale[:, None] * (a[M,K] @ b[N,K]^T) - sub_alpha * sub_rows) with K cut into ``ksplit`` slices that run as tiles of their own
+    (few output tiles, long K: ocn_gemm_nt_splitk); ``rowscale`` fp32 [M], ``sub_rows`` bf16 [M,N], ``scale`` a 1-element fp32 device tensor, each optional"""
+    pa, lda = _chk2d(a, BF16, "a")
+    pb, ldb = _chk2d(b, BF16, "b")
+    po, ldc = _chk2d(out, F32, "out")
+    M, K = a.shape
+    N = b.shape[0]
+    if b.shape[1] != K or tuple(out.shape) != (M, N):
+        raise RuntimeError(f"gemm_nt_splitk: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)}")
+    ws = torch.empty(int(ksplit) * M * ldc, dtype=F32, device=a.device)
+    ps, lds = (0, 0) if sub_rows is None else _chk2d(sub_rows, BF16, "sub_rows")
+    _lib.call("ocn_gemm_nt_splitk", pa, lda, pb, ldb, po, ldc, M, N, K, int(ksplit), ws.data_ptr(), _chk(rowscale, F32, "rowscale"), ps, lds, float(sub_alpha),
+              _chk(scale, F32, "scale"), _stream())
+    return out
+
+
+def scale_rows_bf16(x16, scale):
+    """bf16(scale[r] * x16[r, :])"""
+    px, ldx = _chk2d(x16, BF16, "x16")
+    out = empty(x16.shape, BF16, x16)
+    _lib.call("ocn_scale_rows_bf16", px, ldx, _chk(scale, F32, "scale"), out.data_ptr(), out.stride(0), x16.shape[0], x16.shape[1], _stream())
+    return out
+
+
+def sub_scaled_rows(out, x16, scale, alpha):
+    """out[r, :] -= (alpha / scale[r]) * x16[r, :]   (out fp32 [R, E], a row-contiguous view is fine)"""
+    po, ldo = _chk2d(out, F32, "out")
+    px, ldx = _chk2d(x16, BF16, "x16")
+    _lib.call("ocn_sub_scaled_rows", po, ldo, px, ldx, _chk(scale, F32, "scale"), float(alpha), x16.shape[0], x16.shape[1], _stream())
+    return out
+
+
 DGELU_SCALE, DGELU_OFFSET = 200.0, 0.13  # csrc/ocn_common.h: q = round((gelu' + 0.13) * 200), |error| <= 0.0025
 
 

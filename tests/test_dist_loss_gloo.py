@@ -50,8 +50,12 @@ class CpuPairTerm:
     def dX(self):
         return self.s * self.G @ self.Y
 
-    def dY(self):
-        return self.G.t() @ (self.s * self.X)
+    def dY(self, into=None):
+        out = self.G.t() @ (self.s * self.X)
+        if into is not None:
+            into.copy_(out)
+            return into
+        return out
 
 
 def _worker(rank, world, port, q):

@@ -691,23 +691,29 @@ def test_ops_fail_loudly_on_cpu_tensors(dev):
         ops.gemm_nt(ops.EPI_F32, a, a, torch.zeros(8, 8, device=dev))
 
 
-@pytest.mark.parametrize("R,N,E,off", [(4096, 32768, 512, 3 * 4096), (4096, 4096, 512, 0), (300, 1000, 128, 256), (2048, 16384, 768, 2048)])
-def test_fused_logits_cross_entropy(dev, R, N, E, off):
-    """ocn_fused_logits_ce (no materialised logits; the row-sharded global loss of config 3 is [4096 x 32768 x 512]) against fp32
-    torch on the same bf16 operands: loss within 1e-5 relative, G = softmax * grad_scale within one bf16 rounding of the fp32 value (+2e-3 of
-    the largest |G| in absolute terms: exp of a recomputed logit), sum((softmax - onehot) * grad_scale * logits) within 2e-4 relative."""
+@pytest.mark.parametrize("R,N,E,off,scale", [(4096, 32768, 512, 3 * 4096, 14.2857), (4096, 4096, 512, 0, 14.2857), (300, 1000, 128, 256, 14.2857), (2048, 16384, 768, 2048, 100.0),
+                                             (4096, 4096, 512, 0, 100.0), (512, 2048, 256, 1024, 400.0)])
+def test_fused_logits_cross_entropy(dev, R, N, E, off, scale):
+    """ocn_fused_logits_ce (no materialised logits, ONE pass of the GEMM since round 6; the row-sharded global loss of config 3 is [4096 x 32768 x 512])
+    against fp32 torch on the same bf16 operands: loss within 1e-5 relative; the softmax part of the gradient, G * rowscale[:, None], within one bf16
+    rounding of softmax * grad_scale (+2e-3 of the largest value in absolute terms); sum((softmax - onehot) * grad_scale * logits) within 2e-4 relative.
+    Scale 100 = the clamp of the reference's recipe (image_text_task.py:91-101); scale 400 with the label pair ANTI-aligned in a quarter of the rows drives
+    those rows out of the shifted sums' range and through the exact fix-up kernel."""
     from open_clip_amd import ops
     g = torch.Generator(device=dev).manual_seed(R + N)
     x = torch.nn.functional.normalize(torch.randn(R, E, device=dev, generator=g), dim=-1)
     y = torch.nn.functional.normalize(torch.randn(N, E, device=dev, generator=g), dim=-1)
-    xs16, y16 = bf(x * 14.2857), bf(y)
+    if scale > 100:  # rows 0, 4, 8, ...: the label is the opposite of the image feature (logit -scale), every other column near 0: all under the shift's range
+        y[off:off + R:4] = -x[::4]
+    xs16, y16 = bf(x * scale), bf(y)
     ldg = (N + 63) // 64 * 64
     G = torch.zeros(R, ldg, dtype=torch.bfloat16, device=dev)
     acc = torch.zeros(2, device=dev)
     ls, gs = 0.5 / R, 0.5 / R
     assert ops.fused_logits_ce_supported(R, N, E)
-    ops.fused_logits_ce(xs16, y16, G, N, off, ls, gs, acc[0:1], acc[1:2])
+    rowscale = ops.fused_logits_ce(xs16, y16, G, N, off, ls, gs, acc[0:1], acc[1:2])
     torch.cuda.synchronize()
+    assert rowscale.shape == (R,) and bool(torch.isfinite(rowscale).all()) and bool((rowscale > 0).all())
     loss_ref, ds_ref, worst, bad, gmax = 0.0, 0.0, 0.0, 0, 0.0
     for r0 in range(0, R, 512):
         sl = slice(r0, min(R, r0 + 512))
@@ -719,14 +725,14 @@ def test_fused_logits_cross_entropy(dev, R, N, E, off):
         Gfull = Gref.clone()
         Gfull[torch.arange(lg.shape[0]), lab] -= 1
         ds_ref += float((Gfull * gs * lg).sum())  # sum((softmax - onehot) * grad_scale * logits): the whole gradient
-        Gref *= gs                                 # G itself holds softmax * grad_scale only (the onehot part is the caller's, exact)
-        got = G[sl, :N].float()
+        Gref *= gs                                 # G * rowscale holds softmax * grad_scale only (the onehot part is the caller's, exact)
+        got = G[sl, :N].float() * rowscale[sl, None]
         gmax = max(gmax, float(Gref.abs().max()))
         bad += int(((got - Gref).abs() > Gref.abs() * 2.0 ** -7 + 2e-3 * float(Gref.abs().max())).sum())
         worst = max(worst, rel_l2(got, Gref))
-    _report(f"fused_logits_ce[{R}x{N}x{E}] loss {float(acc[0]):.6f} ref {loss_ref:.6f} dscale {float(acc[1]):.6e} ref {ds_ref:.6e} G rel_l2 {worst:.3e}")
+    _report(f"fused_logits_ce[{R}x{N}x{E}, scale {scale:g}] loss {float(acc[0]):.6f} ref {loss_ref:.6f} dscale {float(acc[1]):.6e} ref {ds_ref:.6e} G rel_l2 {worst:.3e}")
     assert abs(float(acc[0]) - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-6
-    assert abs(float(acc[1]) - ds_ref) <= 2e-4 * abs(ds_ref) + 1e-7
+    assert abs(float(acc[1]) - ds_ref) <= 2e-4 * abs(ds_ref) + 1e-6
     assert bad == 0 and worst <= 5e-3
     assert float(G[:, N:].abs().sum()) == 0.0
 
@@ -915,3 +921,42 @@ def test_gemm_ragged_rows(dev, M):
         refw += (out[r0:r0 + 16384].float().t() @ a[r0:r0 + 16384].float()).double()
     check(f"gemm_tn ragged M={M} dW", dw, refw, rel=2e-4)
     check(f"gemm_tn ragged M={M} dbias", db, out.float().sum(0).double(), rel=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 32768), (4096, 768, 16384), (1024, 1024, 8192), (2500, 264, 4096)])
+def test_gemm_nt_split_k(dev, M, N, K):
+    """ocn_gemm_nt_splitk (round 6: the loss's G @ Y at one rank's share of the 8-GPU loss has 32 output tiles and K = 32768) against fp32 torch: the plain
+    product, and with the reduction's riders -- per-row scale, bf16 rows subtracted with a factor, a device-resident scale"""
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=g)).to(dev)
+    b = bf(torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    ks = ops.gemm_nt_splitk_plan(M, N, K)
+    assert ks >= 2 and K % (128 * ks) == 0, ks
+    ref = a.float() @ b.float().t()
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_nt_splitk(a, b, out, ks)
+    check(f"gemm_nt_splitk[{M}x{N}x{K}, {ks} slices]", out, ref, rel=2e-5)
+    rs = (torch.rand(M, generator=g) + 0.5).to(dev)
+    sub = bf(torch.randn(M, N, generator=g)).to(dev)
+    sc = torch.tensor([3.25], device=dev)
+    out2 = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_nt_splitk(a, b, out2, ks, rowscale=rs, sub_rows=sub, sub_alpha=0.125, scale=sc)
+    check(f"gemm_nt_splitk[{M}x{N}x{K}] with row scale, subtracted rows, device scale", out2, 3.25 * (rs[:, None] * ref - 0.125 * sub.float()), rel=2e-5)
+    # a shape that fills the chip is not split
+    assert ops.gemm_nt_splitk_plan(32768, 512, 32768) == 1 and ops.gemm_nt_splitk_plan(4096, 512, 1024) == 1
+
+
+def test_row_scale_helpers(dev):
+    from open_clip_amd import ops
+    g = torch.Generator().manual_seed(5)
+    R, E = 1000, 512
+    x16 = bf(torch.randn(R, E, generator=g)).to(dev)
+    sc = (torch.rand(R, generator=g) * 1e-3 + 1e-6).to(dev)
+    got = ops.scale_rows_bf16(x16, sc)
+    assert torch.equal(got, (x16.float() * sc[:, None]).to(torch.bfloat16))
+    big = torch.randn(R + 7, E, generator=g).to(dev)
+    want = big.clone()
+    want[3:3 + R] -= (0.5 / sc)[:, None] * x16.float()
+    ops.sub_scaled_rows(big[3:3 + R], x16, sc, 0.5)
+    check("sub_scaled_rows", big, want, rel=1e-6)

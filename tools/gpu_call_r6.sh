@@ -47,4 +47,13 @@ if has mfma; then
   python $GRAFT_REPO_ROOT/tools/pmc_mfma.py $O/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv > $O/${TAG}_pmc_mfma_util.txt 2>&1
   rm -f $O/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES.csv; stamp mfma
 fi
+if has logits; then  # the loss at config 3's sizes: wall times un-profiled first, then per kernel and form under rocprofv3
+  timeout 300 python $GRAFT_REPO_ROOT/tools/logits_probe.py sharded naive local 2>&1 | grep -v "^/opt" > $O/${TAG}_logits_wall.txt
+  for f in sharded naive; do
+    timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_logits_$f -o t -- python $GRAFT_REPO_ROOT/tools/logits_probe.py $f > /dev/null 2>&1
+    python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof_logits_$f -name "*.db" | head -1) 2>&1 | head -24 > $O/${TAG}_logits_kernel_stats_$f.txt
+  done
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_logits -o t -- python $GRAFT_REPO_ROOT/tools/logits_probe.py sharded naive local > $O/${TAG}_logits_probe.txt 2>&1
+  python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $(find /tmp/prof_logits -name "*.db" | head -1) > $O/${TAG}_logits_kernel_stats.txt 2>&1; stamp logits
+fi
 echo "end +$(( $(date +%s) - t0 )) s" >> $O/${TAG}_timeline.txt
