@@ -302,3 +302,80 @@ def test_sigliploss_distributed_at_config5_size(monkeypatch):
         assert abs(float(br.grad) - float(ref["dbias"])) <= 1e-3 * abs(float(ref["dbias"])) + 1e-7
         cm = max(_rel(Ir.grad.sum(0), ref["dI"].sum(0)), _rel(dT_all.sum(0), ref["dT"].sum(0)))
         assert cm <= 5e-2, cm
+
+
+# ---- 4. the two native-only approximations of the MLP epilogues, as an ablation of the reference policy ---------------------------------------------------
+def test_gelu_polynomial_and_8bit_saved_derivative_cost_no_parity_digit():
+    """two approximations ride on every native step and exist nowhere in the reference -- the GELU evaluated through a degree-17 polynomial normal
+    CDF (csrc/ocn_common.h::gelu_both_poly4, |Phi error| 1.24e-5) and its derivative saved for the backward in 8-bit fixed point (q = round((gelu' + 0.13) * 200),
+    |error| <= 0.0025).  Grafted ONE AT A TIME into the reference's own policy (the eager autocast step of oracle/torch_eager.py, ViT-B-32 at batch 1024, against the
+    fp32 reference of the same step): the medians of the 1-D and of the matrix gradients' errors must not move by more than 3 % -- the bf16 operands of the GEMMs
+    dominate both by two orders of magnitude.  (Until round 6 this lived in tools/parity_ablation.py, outside the suite.)"""
+    import math
+    import os
+    import re
+    import torch.nn.functional as F
+    from oracle import gpu_fp32, torch_eager
+    cfg = get_model_config("ViT-B-32")
+    B = 1024
+    state = init_state_dict(cfg, seed=0, perturb=True)
+    batch = synthetic_batch(cfg, B, seed=1234)
+    _, ref = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=256)
+    ref = {k: v.cpu() for k, v in ref.items()}
+    torch.cuda.empty_cache()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open_clip_amd", "csrc", "ocn_common.h")).read()
+    body = hdr[hdr.index("void gelu_both_poly4"):]
+    body = body[:body.index("\n}\n")]
+    first = re.search(r"q = u \* ([-0-9.e+]+)f \+ ([-0-9.e+]+)f;", body)
+    coeffs = [float(first.group(1)), float(first.group(2))] + [float(c) for c in re.findall(r"q = q \* u \+ ([-0-9.e+]+)f;", body)]
+    assert len(coeffs) == 9
+
+    class Gelu(torch.autograd.Function):
+        """forward: exact erf GELU or the kernel's polynomial form; backward: the derivative as the native path keeps it (fp32 from the fp32 pre-activation,
+        then exact or in the 8-bit code)"""
+        @staticmethod
+        def forward(ctx, x, poly, q8):
+            xf = x.float()
+            if poly:
+                xc = xf.clamp(-4.25, 4.25)
+                u = xc * xc
+                q = u * coeffs[0] + coeffs[1]
+                for c in coeffs[2:]:
+                    q = q * u + c
+                cdf = xc * q + 0.5
+                d = (xc * 0.39894228040143268) * torch.exp2(xf * xf * -0.72134752044448170) + cdf
+                y = xf * cdf
+            else:
+                d = 0.5 * (1 + torch.erf(xf / math.sqrt(2.0))) + xf * torch.exp(-0.5 * xf * xf) / math.sqrt(2 * math.pi)
+                y = F.gelu(xf)
+            if q8:
+                d = torch.round((d + 0.13) * 200.0).clamp_(0, 255).to(torch.uint8)
+            ctx.q8 = q8
+            ctx.save_for_backward(d)
+            return y.to(x.dtype)
+
+        @staticmethod
+        def backward(ctx, dy):
+            (d,) = ctx.saved_tensors
+            d = d.float() / 200.0 - 0.13 if ctx.q8 else d
+            return (dy.float() * d).to(dy.dtype), None, None
+
+    med = lambda v: sorted(v)[len(v) // 2]
+    res = {}
+    real_gelu = torch_eager.F.gelu
+    for tag, poly, q8 in (("reference policy (erf GELU, derivative recomputed)", None, None), ("derivative saved exactly", False, False),
+                          ("derivative in the 8-bit code", False, True), ("polynomial CDF + 8-bit derivative (the native epilogues)", True, True)):
+        try:
+            if poly is not None:
+                torch_eager.F.gelu = lambda x, p=poly, q=q8: Gelu.apply(x, p, q)
+            _, grads = torch_eager.amp_step_grads(cfg, state, batch["image"].cuda(), batch["text"].cuda())
+        finally:
+            torch_eager.F.gelu = real_gelu
+        rel = {k: _rel(grads[k], ref[k]) for k in ref}
+        res[tag] = (med([v for k, v in rel.items() if ref[k].ndim <= 1]), med([v for k, v in rel.items() if ref[k].ndim >= 2]))
+        _report(f"gelu ablation [ViT-B-32,B{B}] {tag:58s} median rel_l2 of the 1-D gradients {res[tag][0]:.4e}, of the matrices {res[tag][1]:.4e}")
+        del grads
+        torch.cuda.empty_cache()
+    base = res["reference policy (erf GELU, derivative recomputed)"]
+    for tag, (m1, m2) in res.items():
+        assert m1 <= 1.03 * base[0] and m2 <= 1.03 * base[1], (tag, m1, m2, base)
