@@ -308,19 +308,21 @@ def test_sigliploss_distributed_at_config5_size(monkeypatch):
 def test_gelu_polynomial_and_8bit_saved_derivative_cost_no_parity_digit():
     """two approximations ride on every native step and exist nowhere in the reference -- the GELU evaluated through a degree-17 polynomial normal
     CDF (csrc/ocn_common.h::gelu_both_poly4, |Phi error| 1.24e-5) and its derivative saved for the backward in 8-bit fixed point (q = round((gelu' + 0.13) * 200),
-    |error| <= 0.0025).  Grafted ONE AT A TIME into the reference's own policy (the eager autocast step of oracle/torch_eager.py, ViT-B-32 at batch 1024, against the
-    fp32 reference of the same step): the medians of the 1-D and of the matrix gradients' errors must not move by more than 3 % -- the bf16 operands of the GEMMs
-    dominate both by two orders of magnitude.  (Until round 6 this lived in tools/parity_ablation.py, outside the suite.)"""
+    |error| <= 0.0025).  Grafted ONE AT A TIME into the reference's own policy (the eager autocast step of oracle/torch_eager.py, ViT-B-32 at the bench's batch 4096,
+    against the fp32 reference of the same step): the medians of the 1-D and of the matrix gradients' errors must not move by more than 3 % -- the bf16 operands of
+    the GEMMs dominate both by two orders of magnitude.  (Until round 6 this lived in tools/parity_ablation.py, outside the suite.  Batch 4096 because eager autocast's
+    own error grows steeply below it -- medians 1.4e-2 at 4096, 4.3e-2 at 2048, 1.0e-1 at 1024: its bf16 cross-entropy loses the label entry's p like the native loss
+    did until round 4 -- and would bury what is measured here; the native step stands at 1.0e-2 ... 1.7e-2 over the same batches.)"""
     import math
     import os
     import re
     import torch.nn.functional as F
     from oracle import gpu_fp32, torch_eager
     cfg = get_model_config("ViT-B-32")
-    B = 1024
+    B = 4096
     state = init_state_dict(cfg, seed=0, perturb=True)
     batch = synthetic_batch(cfg, B, seed=1234)
-    _, ref = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=256)
+    _, ref = gpu_fp32.step_reference(cfg, state, batch["image"], batch["text"], chunk=512)
     ref = {k: v.cpu() for k, v in ref.items()}
     torch.cuda.empty_cache()
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open_clip_amd", "csrc", "ocn_common.h")).read()
@@ -329,6 +331,7 @@ def test_gelu_polynomial_and_8bit_saved_derivative_cost_no_parity_digit():
     first = re.search(r"q = u \* ([-0-9.e+]+)f \+ ([-0-9.e+]+)f;", body)
     coeffs = [float(first.group(1)), float(first.group(2))] + [float(c) for c in re.findall(r"q = q \* u \+ ([-0-9.e+]+)f;", body)]
     assert len(coeffs) == 9
+    real_gelu = torch_eager.F.gelu  # (torch_eager.F IS torch.nn.functional: the patch below replaces F.gelu itself)
 
     class Gelu(torch.autograd.Function):
         """forward: exact erf GELU or the kernel's polynomial form; backward: the derivative as the native path keeps it (fp32 from the fp32 pre-activation,
@@ -347,7 +350,7 @@ def test_gelu_polynomial_and_8bit_saved_derivative_cost_no_parity_digit():
                 y = xf * cdf
             else:
                 d = 0.5 * (1 + torch.erf(xf / math.sqrt(2.0))) + xf * torch.exp(-0.5 * xf * xf) / math.sqrt(2 * math.pi)
-                y = F.gelu(xf)
+                y = real_gelu(xf)
             if q8:
                 d = torch.round((d + 0.13) * 200.0).clamp_(0, 255).to(torch.uint8)
             ctx.q8 = q8
@@ -362,7 +365,6 @@ def test_gelu_polynomial_and_8bit_saved_derivative_cost_no_parity_digit():
 
     med = lambda v: sorted(v)[len(v) // 2]
     res = {}
-    real_gelu = torch_eager.F.gelu
     for tag, poly, q8 in (("reference policy (erf GELU, derivative recomputed)", None, None), ("derivative saved exactly", False, False),
                           ("derivative in the 8-bit code", False, True), ("polynomial CDF + 8-bit derivative (the native epilogues)", True, True)):
         try:
