@@ -211,7 +211,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3))) void 
 // TWO_PASS: dV and dK in two sub-passes over the query blocks (S is recomputed in the second: +4 of 16 MFMAs per block) so that only ONE
 // pair of 32 x 64 accumulators is live at a time and each result leaves through the wave's own rows of the V image as soon as it is
 // complete -- the live set fits 168 registers (three waves per SIMD, six workgroups of two waves per CU instead of four) without spills.
-template <int MAXT, int WPE, bool TWO_PASS = false>
+// DELTA_P (round 6; sequences of at most two key blocks: the image tower's 50 tokens, the short buckets of the packed text tower): the softmax
+// backward's row term delta_q = sum_d dO[q,d] O[q,d] is taken as sum_j P[q,j] dP[q,j] -- the same number (O = P V, dP = dO V^T), formed from the P and dP
+// tiles phase A has in registers anyway.  O is then not read at all: 2C of the kernel's 16C bytes per token, and the wave's per-lane global loads of its
+// O rows, go away; P enters unrounded instead of through O's bf16 rounding.
+template <int MAXT, int WPE, bool TWO_PASS = false, bool DELTA_P = false>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                          bf16* __restrict__ dqkv, const int32_t* __restrict__ seq_off, int Lmax, int H, int causal,
@@ -263,14 +267,14 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 qf[s] = *(const bf16x8*)(qbase + (size_t)qrow * rs + (s * 2 + lh) * 8);
-                of[s] = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
+                if constexpr (!DELTA_P) of[s] = *(const bf16x8*)(obase + (size_t)qrow * C + (s * 2 + lh) * 8);
             }
             lse_q = lse[((size_t)b * H + hd) * Lmax + qrow] * LOG2E;  // exp2 units
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 qf[s] = frag_rows(sA, active ? query : lr, s, lane);
-                of[s] = qf[s];
+                if constexpr (!DELTA_P) of[s] = qf[s];
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -279,15 +283,63 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             dof[s] = frag_rows(sC, active ? query : lr, s, lane);
+            if constexpr (!DELTA_P) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[s][e]);
+                for (int e = 0; e < 8; ++e) delta_q += bf2f(dof[s][e]) * bf2f(of[s][e]);
+            }
         }
+        const int nkb = ((ablate & 2) || !active) ? 0 : (causal ? qb + 1 : nb);
+        if constexpr (DELTA_P) {
+            // every key block's P and dP first (at most two: 64 registers), delta from them, then dS and the dQ products
+            f32x16 pk[2], dpk[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                pk[kb] = zero16();
+                dpk[kb] = zero16();
+                if (kb < nkb) {
+                    f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        st = mfma32(frag_rows(sA, kb * 32 + lr, s, lane), qf[s], st);
+                        dp = mfma32(frag_rows(sB, kb * 32 + lr, s, lane), dof[s], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb * 32 + mfma32_row(r, lane);
+                        const bool ok = key < L && query < L && (!causal || key <= query);
+                        const float e = fast_exp2(st[r] * sc - lse_q);
+                        const float p = ok ? e : 0.f;
+                        pk[kb][r] = p;
+                        dpk[kb][r] = dp[r];
+                        delta_q = fmaf(p, dp[r], delta_q);
+                    }
+                }
+            }
+            delta_q += __shfl_xor(delta_q, 32, 64);  // a query's keys sit in both half-waves
+            if (lh == 0) {
+                sLse[query] = lse_q;
+                sDelta[query] = delta_q;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb < nkb) {
+                    f32x16 st;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = pk[kb][r] * (dpk[kb][r] - delta_q) * scale;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const bf16x8 dsf = pack8(st, t);
+                        dq0 = mfma32(frag_cols(sA, kb * 32, t, 0, lane), dsf, dq0);
+                        dq1 = mfma32(frag_cols(sA, kb * 32, t, 1, lane), dsf, dq1);
+                    }
+                }
+            }
+        } else {
         delta_q += __shfl_xor(delta_q, 32, 64);
         if (lh == 0) {  // phase B (behind the next barrier) reads these for every query
             sLse[query] = lse_q;
             sDelta[query] = delta_q;
         }
-        const int nkb = ((ablate & 2) || !active) ? 0 : (causal ? qb + 1 : nb);
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16 st = zero16(), dp = zero16();
 #pragma unroll
@@ -309,6 +361,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))
                 dq0 = mfma32(frag_cols(sA, kb * 32, t, 0, lane), dsf, dq0);
                 dq1 = mfma32(frag_cols(sA, kb * 32, t, 1, lane), dsf, dq1);
             }
+        }
         }
     }
 
@@ -644,7 +697,13 @@ int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const fl
     // two-pass dK / dV build (168 registers, three waves per SIMD, no spills): developer knob 2 = 4 selects it, 2 = 5 forces the one-pass
     // build; default: see OCN_ATTN_BWD_TWO_PASS_DEFAULT
     const bool two_pass = g_ocn_tuning[2] == 4 || (g_ocn_tuning[2] != 5 && OCN_ATTN_BWD_TWO_PASS_DEFAULT && nw <= 4);
-    if (nw <= 4 && two_pass) {
+    // The CALL's longest sequence has at most two key blocks (the image tower's 50 tokens): delta from P and dP, O is not read.  Decided per call, not per
+    // bucket: results must not depend on the bucketing, and the packed text tower (Lmax = 77) must stay bit-identical to the dense one, whose kernels
+    // read O.  (developer knob 2 = 6: the O-reading form, A/B)
+    if (ocn_cdiv(L, 32) <= 2 && two_pass && g_ocn_tuning[2] != 6) {
+        hipLaunchKernelGGL((attn_bwd_kernel<256, 3, true, true>), dim3(nseq * H), dim3(nw * 64), lds, st, (const bf16*)qkv,
+                           (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, seq_off, L, H, causal, scale, g_ocn_tuning[1], order, order_off);
+    } else if (nw <= 4 && two_pass) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<256, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
