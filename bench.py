@@ -288,8 +288,9 @@ def torch_eager_baseline(model_name, batch_size, dev):
     cfg = get_model_config(model_name)
     batch = synthetic_batch(cfg, batch_size, seed=1234, device=dev)
     torch.cuda.reset_peak_memory_stats()
-    sec, loss, peak = torch_eager.time_step(cfg, init_state_dict(cfg, seed=0), batch, steps=4, warmup=2)
-    return {"value": round(batch_size / sec, 1), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 2), "batch": batch_size, "final_loss": round(loss, 4),
+    sec, loss, peak = torch_eager.time_step(cfg, init_state_dict(cfg, seed=0), batch, steps=5, warmup=2)
+    return {"value": round(batch_size / sec, 1), "unit": "pairs/s", "ms_per_step": round(sec * 1e3, 2), "ms_per_step_is": "median of 5 separately timed steps",
+            "s_per_step_sorted": getattr(torch_eager.time_step, "last_all", None), "batch": batch_size, "final_loss": round(loss, 4),
             "peak_hbm_gb": round(peak / 1e9, 1),
             "what": "same step (ViT tower + text tower + ClipLoss + backward + torch.optim.AdamW + clamp) as plain PyTorch-ROCm eager ops under "
                     "torch.amp.autocast(bf16): F.linear / F.scaled_dot_product_attention / F.layer_norm / F.gelu / F.cross_entropy on this GPU "

@@ -34,7 +34,7 @@ struct GemmNtArgs {
     float ce_grad_scale;
 };
 // internal epilogues of the persistent NT kernel (not part of enum ocn_epilogue): the logits tile never leaves the registers
-enum { OCN_EPI_CE_ONEPASS = 9 };  // (5, 6: the two-pass statistics / gradient epilogues of rounds 2-5, removed)
+enum { OCN_EPI_CE_ONEPASS = 9, OCN_EPI_CE_ONEPASS_FULL = 10 };  // _FULL: M, N multiples of 256, no masks  // (5, 6: the two-pass statistics / gradient epilogues of rounds 2-5, removed)
 
 // chunk swizzle for 128-byte LDS rows: bijection on 3 bits built from row bits 1..3, chosen so that
 // (a) the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots and

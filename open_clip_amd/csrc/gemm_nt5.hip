@@ -176,7 +176,7 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     constexpr bool IS_GELU = (EPI == OCN_EPI_BIAS_GELU || EPI == OCN_EPI_BIAS_QUICKGELU);  // two-output activation epilogues
     constexpr bool IS_DGELU = (EPI == OCN_EPI_DGELU);
     constexpr bool IS_RES16 = (EPI == OCN_EPI_BIAS_RESID_BF16);  // bf16 residual stream: out = bf16(resid + bf16(acc + bias)), added behind the transpose
-    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || IS_RES16 || EPI == OCN_EPI_CE_ONEPASS);
+    constexpr bool BF16_STAGED = (EPI == OCN_EPI_BF16 || IS_GELU || IS_DGELU || IS_RES16 || EPI == OCN_EPI_CE_ONEPASS || EPI == OCN_EPI_CE_ONEPASS_FULL);
     constexpr bool OUT_F32 = (EPI == OCN_EPI_BIAS_RESID_F32 || EPI == OCN_EPI_F32);
     // developer knobs 32 / 128 (OCN_DEV_BUILD only): zero-sized descriptors -- the epilogue's stores (32) / operand loads (128) are still issued
     // but the bounds check drops them before they reach memory: what the tile loop costs with a free memory system (results wrong)
@@ -213,15 +213,17 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
     // logit, clamped from below so that no entry can overflow) is written as the bf16 matrix G' and its row sums S_i = sum_j e_ij, SL_i = sum_j e_ij l_ij
     // as per-strip partials; softmax = G' / S_i is never formed: the 1 / S_i goes into the consumers' row scales (loss.py::_PairTerm.dX / dY).  The
     // logits GEMM runs ONCE instead of twice (statistics pass + gradient pass): 3 GEMMs per direction of the loss instead of 4.
-    if constexpr (EPI == OCN_EPI_CE_ONEPASS) {
-        // (measured and not adopted, round 6: an unmasked copy of this loop for interior tiles behind a uniform branch -- the second copy of the epilogue
-        // costs more registers than the two compares and selects per element it saves: 187 -> 333 us on [4096 x 32768 x 512])
+    if constexpr (EPI == OCN_EPI_CE_ONEPASS || EPI == OCN_EPI_CE_ONEPASS_FULL) {
+        // _FULL: M and N are multiples of 256 (every tile is whole: chosen by the HOST, a separate instantiation): no row / column masks.
+        // (measured and not adopted, round 6: an unmasked copy of this loop for interior tiles behind a uniform branch INSIDE one kernel -- the second copy
+        // of the epilogue costs more registers than the two compares and selects per element it saves: 187 -> 333 us on [4096 x 32768 x 512])
+        constexpr bool MASKED = (EPI == OCN_EPI_CE_ONEPASS);
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int row = m0 + wm * 128 + ha * 64 + s * 32 + lr;
-                const bool rv = row < a.M;
+                const bool rv = !MASKED || row < a.M;
                 const float c2 = rv ? a.ce_shift2[row] : 0.f;  // c_i * log2(e)
                 float se = 0.f, sel = 0.f;
 #pragma unroll
@@ -230,7 +232,8 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
                     for (int r = 0; r < 16; ++r) {
                         const int col = gn_w + hb * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
                         const float v = acc[ha][s][hb][r];
-                        const float e = (rv && col < a.N) ? __builtin_amdgcn_exp2f(fmaf(v, 1.4426950408889634f, -c2)) : 0.f;
+                        float e = __builtin_amdgcn_exp2f(fmaf(v, 1.4426950408889634f, -c2));
+                        if constexpr (MASKED) e = (rv && col < a.N) ? e : 0.f;
                         se += e;
                         sel = fmaf(e, v, sel);
                         acc[ha][s][hb][r] = e;  // stored as bf16 by the staged path below
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // K-tile (16 MFMAs per wave: A x (B0, B1) with the B fragments read as they are used) and one barrier: the slot of K-tile g is free once
     // every wave has read its last fragments, which is where the barrier sits, and is refilled right behind it -- B two K-tiles ahead (it comes
     // from L2), A four K-tiles ahead through the two A units a half tile does not otherwise need (it comes from HBM).
-    if constexpr (EPI != OCN_EPI_CE_ONEPASS) if (a.tail_n > 0) {
+    if constexpr (EPI != OCN_EPI_CE_ONEPASS && EPI != OCN_EPI_CE_ONEPASS_FULL) if (a.tail_n > 0) {
         int t = -1, h = 0;
         if ((int)blockIdx.x < a.tail_n) t = (int)blockIdx.x;
         else if ((int)blockIdx.x >= a.tail_partner && (int)blockIdx.x < a.tail_partner + a.tail_n) { t = (int)blockIdx.x - a.tail_partner; h = 1; }
@@ -918,7 +921,7 @@ int launch5(GemmNtArgs a, hipStream_t st) {
     a.tail_first = a.tail_n = a.tail_partner = 0;
     {
         const int R = a.ntiles % grid, P = (R + 7) / 8 * 8;
-        constexpr bool ce = (EPI == OCN_EPI_CE_ONEPASS);  // its row statistics are laid out per whole tile
+        constexpr bool ce = (EPI == OCN_EPI_CE_ONEPASS || EPI == OCN_EPI_CE_ONEPASS_FULL);  // its row statistics are laid out per whole tile
         if (!ce && a.ksplit == 1 && a.ntiles > grid && R > 0 && R + P <= grid && (a.K / 64) % 4 == 0 && !ABL(a, 0x200000)) {
             a.tail_first = a.ntiles - R;
             a.tail_n = R;
@@ -994,6 +997,7 @@ int ocn_launch_nt5(int epilogue, const GemmNtArgs& a, hipStream_t st) {
         case OCN_EPI_DGELU: return launch5<OCN_EPI_DGELU>(a, st);
         case OCN_EPI_F32: return launch5<OCN_EPI_F32>(a, st);
         case OCN_EPI_CE_ONEPASS: return launch5<OCN_EPI_CE_ONEPASS>(a, st);
+        case OCN_EPI_CE_ONEPASS_FULL: return launch5<OCN_EPI_CE_ONEPASS_FULL>(a, st);
     }
     return 1;
 }

@@ -293,7 +293,7 @@ extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ld
     hipLaunchKernelGGL(ce_prep_rows_kernel, dim3(ocn_cdiv(R, 4)), dim3(256), 0, st, (const bf16*)X, ldx, (const bf16*)Y, ldy, R, E, label_offset, ymax2,
                        a.ce_label_logit, shift2);
     OCN_CHECK_LAUNCH("ocn_fused_logits_ce");
-    const int rc = ocn_launch_nt5(OCN_EPI_CE_ONEPASS, a, st);
+    const int rc = ocn_launch_nt5((R % 256 == 0 && N % 256 == 0) ? OCN_EPI_CE_ONEPASS_FULL : OCN_EPI_CE_ONEPASS, a, st);
     if (rc != 0) { if (rc > 0) ocn_set_error("ocn_fused_logits_ce: shape not supported by the persistent GEMM"); return rc > 0 ? OCN_ERR_UNSUPPORTED : rc; }
     hipLaunchKernelGGL(ce_finish_kernel, dim3(ocn_cdiv(R, 16)), dim3(256), 0, st, a.ce_stats, a.ce_label_logit, shift2, rowscale, bad, R, parts, loss_scale,
                        grad_scale, loss_sum, dscale_sum);

@@ -130,13 +130,20 @@ def time_step(cfg, state, batch, steps=5, warmup=2, lr=5e-4):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    # every step timed on its own, the MEDIAN reported: one step that pays for an allocator growth or a library's first-use tuning must not set the
+    # baseline (round 6: one run of four averaged 1.3 s per step on a box whose other runs gave 0.5 s)
+    evs = []
     for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         loss = step()
-    e1.record()
+        e1.record()
+        evs.append((e0, e1))
     torch.cuda.synchronize()
+    times = sorted(a.elapsed_time(b) / 1e3 for a, b in evs)
+    time_step.last_all = [round(t, 4) for t in times]
+    sec = times[len(times) // 2]
     peak = torch.cuda.max_memory_allocated()
     del model, opt
     torch.cuda.empty_cache()
-    return e0.elapsed_time(e1) / 1e3 / steps, float(loss.detach()), peak
+    return sec, float(loss.detach()), peak
