@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16* __restrict__ 
 
 // DR: the residual gradient -- 0 none, 1 bf16, 2 fp32 (NativeCLIP(image_stream="bf16-fp32grad")); dx32 optional (DX32), dx16 always
 template <int NV>
-constexpr int ln_bwd16_waves() { return NV <= 2 ? 16 : (NV == 3 ? 12 : 8); }  // two packed rows per wave cost registers: fewer waves than ln_bwd_waves
+constexpr int ln_bwd16_waves() { return NV <= 2 ? 16 : (NV == 3 ? 12 : 8); }  // (NV = 5: 172-234 registers at 8 waves, no spills)  // two packed rows per wave cost registers: fewer waves than ln_bwd_waves
 
 template <int NV, int DR, bool DX32>
 __global__ __launch_bounds__(ln_bwd16_waves<NV>() * 64) void ln_bwd16_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
@@ -483,8 +483,9 @@ bool launch_bwd(hipStream_t st, const void* dy, int dy_is_f32, const void* x, in
         // the bf16 residual stream (image tower): dy is always the bf16 output of a dgrad GEMM there; the residual gradient is bf16 (the
         // reference's autograd: the gradient of a bf16 tensor is bf16) or the fp32 companion (NativeCLIP(image_stream="bf16-fp32grad"))
         if (dy_is_f32 || dcol) return false;
-        // the pipelined form up to C = 1024 (beyond, the second row's registers spill; developer knob 8 = 2: the one-row-at-a-time kernel, A/B)
-        if constexpr (NV <= 4) if (dx16 && C == NV * 256 && g_ocn_tuning[8] != 2) {
+        // the pipelined form up to C = 1280 (ViT-H-14; 8 waves of up to 256 registers there; beyond, the second row's registers spill; developer knob
+        // 8 = 2: the one-row-at-a-time kernel, A/B)
+        if constexpr (NV <= 5) if (dx16 && C == NV * 256 && g_ocn_tuning[8] != 2) {
             const int G = ln_bwd_grid<NV>(M);  // (the reproducible form's workspace is sized for this grid; rows are grid-strided)
             const dim3 g(G), t(ln_bwd16_waves<NV>() * 64);
 #define OCN_LN_BWD16(DR)                                                                                                                                   \
