@@ -78,6 +78,8 @@ def parse():
                     "(ocn_comm_*); DistributedDataParallel + torch.distributed stay the fallback when the communicator cannot be created")
     ap.add_argument("--torch-comm", action="store_true", help="N > 1: the loss collectives through torch.distributed's process group, too (default for N > 1 with the "
                     "nccl backend: the loss's feature all-gather / reduce-scatter / scalar all-reduce through ocn_comm_*, the gradient all-reduce through DDP)")
+    ap.add_argument("--tile-rescue", choices=("auto", "on", "off"), default="auto", help="the persistent GEMMs' multi-GPU form (ocn_set_tile_rescue: workgroups that "
+                    "finish hand out the shares of workgroups whose CU is held by a collective's kernel); auto = on when N > 1")
     ap.add_argument("--bucket-cap-mb", type=int, default=128)
     ap.add_argument("--data-ranks", type=int, default=1, help="developer: with one process, use the concatenation of the batches R ranks would "
                     "get (what a world_size-R run sees as its global batch; tests/test_bench_gpu.py)")
@@ -563,6 +565,9 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
         pipe.submit(*host_pool[0])
     if args.native:
         args.native_comm = args.native_allreduce = True
+    tile_rescue = args.tile_rescue == "on" or (args.tile_rescue == "auto" and world > 1)
+    from open_clip_amd import ops as _ops
+    _ops.set_tile_rescue(tile_rescue)
     # N > 1 over RCCL: the loss collectives go through the C ABI's communicator by default (north_star: "an RCCL all-gather ... through a thin C-ABI
     # extension"); --torch-comm keeps them on the process group, --native moves the gradient all-reduce there as well
     want_loss_comm = args.native_comm or (world > 1 and args.dist_backend == "nccl" and not args.torch_comm)
@@ -806,6 +811,8 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
                        "gradient_allreduce": ("native per-block in-place all-reduce (open_clip_amd/grad_sync.py)" + (" over RCCL through the C ABI" if native_comm is not None else " over the process group")
                                               if grad_sync is not None else ("DistributedDataParallel" if (world > 1 or args.force_ddp) else "none (one process)")),
                        "loss_collectives": ("C ABI (ocn_comm_*)" + (" on a one-rank communicator" if world == 1 else "")) if loss_comm is not None else ("torch.distributed" if world > 1 else "none"),
+                       "gemm_tile_rescue": ("on: finishing workgroups take over the shares of workgroups that have not started (CUs held by collectives' kernels)"
+                                            if tile_rescue else "off (static shares: one process, nothing else holds CUs)"),
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps, "input": "host_uint8_h2d" if args.h2d else "resident",
                        "image_residual_stream": {"fp32": "fp32 (stricter than the reference's autocast)",
                                                  "bf16": "bf16, stream and gradient (what the reference's autocast runs in the image tower: transformer.py:794, layers.py:23-26)",

@@ -54,8 +54,9 @@ const char* ocn_last_error(void);
 /*   103 (round 6)  bf16 residual stream of the image tower: ocn_layernorm_fwd / ocn_layernorm_bwd / ocn_gather_rows take dtype flags, ocn_gemm_nt
  *                  takes `resid` as void* (fp32 or bf16 by epilogue) and knows OCN_EPI_BIAS_RESID_BF16; new: ocn_comm_count, ocn_comm_sendrecv; ocn_fused_logits_ce is ONE
  *                  pass now: G holds exp(logit - shift), the row scale comes back in `rowscale` (new argument); new: ocn_gemm_nt_splitk[_plan],
- *                  ocn_scale_rows_bf16, ocn_sub_scaled_rows. */
-#define OCN_ABI_VERSION 103
+ *                  ocn_scale_rows_bf16, ocn_sub_scaled_rows.
+ *   104 (round 6)  new: ocn_set_tile_rescue / ocn_get_tile_rescue (no signature changed). */
+#define OCN_ABI_VERSION 104
 int ocn_version(void);
 
 /* ---- GEMMs (MFMA v_mfma_f32_32x32x16_bf16, fp32 accumulate) ------------------------------------
@@ -338,6 +339,17 @@ int ocn_comm_count(void* comm, int* count_out, int* rank_out);
 /* one neighbour exchange (loss.py:226-243 `neighbour_exchange`: one isend + one irecv batched): send [count] to to_rank, recv [count] from from_rank, as
  * one grouped RCCL operation on the caller's stream; dtype as above (0 fp32, 1 bf16, 2 raw bytes) */
 int ocn_comm_sendrecv(void* comm, const void* send, int to_rank, void* recv, int from_rank, int64_t count, int dtype, ocn_stream_t stream);
+
+/* ---- the persistent GEMMs next to other streams' kernels (multi-GPU) ----------------------------
+ * ocn_gemm_nt / ocn_gemm_tn_accum launch one workgroup per CU with a fixed share of the tiles.  A workgroup whose CU is held by another stream's kernel
+ * (RCCL's, during the gradient all-reduce) starts only when a CU frees up and then walks its whole share alone: the launch takes up to twice as long.
+ * ocn_set_tile_rescue(1) (process-wide, takes effect with the next launch) selects the kernels' rescue form: the shares stay static and no atomic enters
+ * the tile loop, but workgroups that finish hand out -- entry by entry, through one counter per workgroup on a per-stream board -- the shares of workgroups
+ * that have not started.  Results: ocn_gemm_nt bit-identical to the static form (every tile is computed once, by whichever workgroup), ocn_gemm_tn_accum
+ * sums the same products with fp32 atomics in a different order, as between any two of its runs; the reproducible wgrad (workspace form) stays static.
+ * Cost without contention: one atomic per workgroup at either end of a launch.  Off by default; open_clip_amd turns it on when world_size > 1. */
+int ocn_set_tile_rescue(int on);
+int ocn_get_tile_rescue(void);
 
 /* ---- self-test probes (used by tests/ to pin the hardware fragment layouts this library assumes) */
 int ocn_probe_mfma32(const void* a_bf16 /*[32,16]*/, const void* b_bf16 /*[32,16] (n,k)*/, float* c /*[32,32]*/,

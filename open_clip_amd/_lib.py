@@ -72,6 +72,7 @@ SIGNATURES = {
     "ocn_comm_allreduce_avg": [_p, _p, _l, _i, _p],
     "ocn_comm_broadcast": [_p, _p, _l, _i, _i, _p],
     "ocn_comm_count": [_p, _p, _p],
+    "ocn_set_tile_rescue": [_i],
     "ocn_comm_sendrecv": [_p, _p, _i, _p, _i, _l, _i, _p],
     "ocn_probe_mfma32": [_p, _p, _p, _p],
     "ocn_probe_tr16": [_p, _p, _p],
@@ -86,9 +87,9 @@ DEBUG_SIGNATURES = {
     "ocn_debug_stream_with_cu_mask": [_p, _i, _p],
 }
 _SPECIAL = {"ocn_last_error": ([], ctypes.c_char_p), "ocn_version": ([], _i), "ocn_gemm_tn_det_workspace_bytes": ([_i, _i, _i], _l),
-            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_gemm_nt_splitk_plan": ([_i, _i, _i], _i), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l)}
+            "ocn_fused_logits_ce_workspace_floats": ([_i, _i], _l), "ocn_gemm_nt_splitk_plan": ([_i, _i, _i], _i), "ocn_layernorm_bwd_det_workspace_floats": ([_i, _i], _l), "ocn_get_tile_rescue": ([], _i)}
 
-ABI_VERSION = 103  # == OCN_ABI_VERSION of include/openclip_hip.h (tests/test_cabi.py compares the two): load() refuses any other library
+ABI_VERSION = 104  # == OCN_ABI_VERSION of include/openclip_hip.h (tests/test_cabi.py compares the two): load() refuses any other library
 
 _lib = None
 _lock = threading.Lock()

@@ -1,5 +1,7 @@
 // Error plumbing, version, and the two hardware-layout probes the tests use.
-#include "ocn_common.h"
+#include <mutex>
+#include <unordered_map>
+#include "gemm_args.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -22,6 +24,38 @@ extern "C" int ocn_set_tuning(int key, int value) {
     OCN_CHECK_ARG(key >= 0 && key < 16, "ocn_set_tuning: key %d out of range", key);
     g_ocn_tuning[key] = value;
     return OCN_OK;
+}
+
+// ---- tile rescue (multi-GPU form of the persistent GEMMs; gemm_nt5.hip / gemm_tn5.hip) ----------------------------------------------------------
+// Off: every workgroup computes its static share and nothing else (the single-GPU kernels, untouched).  On: the launches carry a board of counters
+// through which workgroups that finish hand out the shares of workgroups that have not started (their CU is held by a collective's kernel).
+// Boards come from a per-stream ring (below).
+int g_ocn_tile_rescue = 0;
+extern "C" int ocn_set_tile_rescue(int on) {
+    g_ocn_tile_rescue = on ? 1 : 0;
+    return OCN_OK;
+}
+extern "C" int ocn_get_tile_rescue(void) { return g_ocn_tile_rescue; }
+
+int* ocn_rescue_board(hipStream_t st, int workgroups) {
+    // A ring of OCN_RESCUE_RING boards (2 MiB) per stream, one per launch, zeroed all at once (stream-ordered) every time the ring wraps: no launch has to clean
+    // up behind itself (a "last one out" counter costs 256 same-address atomics at the moment every workgroup finishes).  Not for graph capture: the
+    // ring position is host state.
+    if (!g_ocn_tile_rescue || workgroups > OCN_RESCUE_SLOTS) return nullptr;
+    struct Ring { int* base; unsigned next; };
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, Ring> rings;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = rings.find(st);
+    if (it == rings.end()) {
+        int* b = nullptr;
+        if (hipMalloc((void**)&b, (size_t)OCN_RESCUE_RING * OCN_RESCUE_SLOTS * OCN_RESCUE_STRIDE * sizeof(int)) != hipSuccess) return nullptr;
+        it = rings.emplace(st, Ring{b, 0u}).first;
+    }
+    Ring& r = it->second;
+    const unsigned slot = r.next++ % OCN_RESCUE_RING;
+    if (slot == 0 && hipMemsetAsync(r.base, 0, (size_t)OCN_RESCUE_RING * OCN_RESCUE_SLOTS * OCN_RESCUE_STRIDE * sizeof(int), st) != hipSuccess) return nullptr;
+    return r.base + (size_t)slot * OCN_RESCUE_SLOTS * OCN_RESCUE_STRIDE;
 }
 
 namespace {

@@ -457,7 +457,7 @@ extern "C" int ocn_gemm_nt(int epilogue, const void* A, int lda, const void* B, 
     GemmNtArgs a;
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.out = out; a.bias = bias; a.resid = resid; a.aux = (unsigned char*)aux;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.alpha = alpha;
-    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0; a.ksplit = 1; a.ws_stride = 0;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0; a.ksplit = 1; a.ws_stride = 0; a.rescue = nullptr;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OCN_EPI_BF16: return launch_nt<OCN_EPI_BF16>(a, st);

@@ -24,6 +24,7 @@ struct GemmNtArgs {
     // to out + s * ws_stride elements (out = the caller's workspace of ksplit slabs); 0 / 1 = off
     int ksplit;
     long ws_stride;
+    int* rescue;  // tile-rescue board of this launch (core.hip::ocn_rescue_board): [w] = counter of workgroup w's share, zero at launch; null = off
     // fused logits + cross-entropy epilogue (OCN_EPI_CE_ONEPASS below; ocn_fused_logits_ce in loss.hip)
     float* ce_stats;        // [M][ce_parts][2]: per row and 64-column strip (sum e, sum e * logit), e = exp(logit - shift)
     float* ce_label_logit;  // [M] the logit of the row's label column (host side of the launch only)
@@ -62,7 +63,15 @@ struct GemmTnArgs {
     float* dW2;
     float* dbias2;
     int lda2, ldb2, ldw2, N2, ntile1, ntile_all;
+    int* rescue;  // tile-rescue board (as GemmNtArgs::rescue); a share = the `pieces` sub-chunks of a workgroup's M-chunk
+    int pieces, piece_rows;
 };
+
+// tile rescue (core.hip): a zeroed board for ONE launch on `st` when ocn_set_tile_rescue(1) is in force and the launch has at most OCN_RESCUE_SLOTS workgroups, else null
+// counters per board (= most workgroups of a launch), boards per stream, ints from one counter to the next (measured: one counter per 128-byte line,
+// stride 32, changes nothing -- the owners' claims are hidden behind their prologues either way -- and makes the finishers' scan 32 x as wide)
+constexpr int OCN_RESCUE_SLOTS = 1024, OCN_RESCUE_RING = 512, OCN_RESCUE_STRIDE = 1;
+int* ocn_rescue_board(hipStream_t st, int workgroups);
 
 // hand-scheduled 256x256 TN (wgrad) kernel (gemm_tn5.hip); returns 1 if the shape is not supported by it (caller falls back)
 int ocn_launch_tn5(GemmTnArgs a, hipStream_t st);

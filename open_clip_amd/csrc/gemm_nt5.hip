@@ -415,7 +415,13 @@ OCN_DEV void epilogue5(const GemmNtArgs& a, f32x16 (&acc)[2][2][2], int m0, int 
 // DBG = developer build of the same kernel that logs a per-tile timeline into a.aux (tools/gemm_trace.py; plain bf16
 // epilogue only); the production instantiation folds it away.
 // AUX = cache policy of the epilogue: bit 1 (2) = non-temporal stores, bit 3 (8) = non-temporal loads of the residual / saved operand
-template <int EPI, bool DBG, int AUX = 0>
+// RESCUE (ocn_set_tile_rescue, the multi-GPU form): the static shares stay, but a share whose workgroup has NOT STARTED by the time others finish -- its
+// CU is held by another stream's kernel, e.g. a collective -- is handed out entry by entry to the finishers.  The board a.rescue holds one counter per
+// workgroup: the owner adds RESCUE_BIG ONCE when it starts (what it gets back = the entries finishers already took: it begins behind them, and no
+// finisher can claim from it afterwards), a finisher claims entry k of share w with one atomicAdd(+1) (valid while k < the share's length).  No atomic
+// sits inside the tile loop: the DMA pipeline's counted vmcnt waits retire in issue order and would stall behind one.
+constexpr int RESCUE_BIG = 1 << 20;
+template <int EPI, bool DBG, int AUX = 0, bool RESCUE = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -427,8 +433,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     const int G = gridDim.x;
     // a.tail_n > 0: the launch's last, partial round of tiles is split into HALF tiles (see below); the whole tiles are then exactly a.tail_first / G per
     // workgroup
-    const int my_tiles = a.tail_n > 0 ? a.tail_first / G : (a.ntiles - (int)blockIdx.x + G - 1) / G;
+    auto share_of = [&](int w) { return a.tail_n > 0 ? a.tail_first / G : (a.ntiles - w + G - 1) / G; };  // whole tiles of workgroup w's share
+    int my_tiles = share_of((int)blockIdx.x);
+    int vblk = (int)blockIdx.x, ibase = 0;  // the share this pass works on and its first entry (RESCUE: a finisher's later passes take ONE entry of another share)
     const unsigned lds_base = (unsigned)(size_t)(OCN_LDS char*)smem;
+    int* const box = (int*)(smem + RING_BYTES);  // RESCUE: workgroup-wide mailbox (wave 0's staging area, free outside a tile's epilogue)
+    // The owner's claim is ISSUED here and read behind the first prologue, whose operand fetches cover its latency (a device-scope atomic's round trip is
+    // about what the prologue takes: waited for up front it costs 0.35 % of a training step, 0.5 ms over ~400 launches).  The prologue assumes nothing was
+    // taken; when something was (the workgroup got its CU late), it is repeated behind the entries the finishers hold.
+    int claim = 0;
+    bool fresh = RESCUE;
+    if constexpr (RESCUE) if (threadIdx.x == 0) {
+        // inline asm: hipcc's own atomicAdd is consumed on the spot (its wave-reduction wrapper reads the result back at once)
+        const int* cptr = a.rescue + blockIdx.x * OCN_RESCUE_STRIDE;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(claim) : "v"(0), "v"(RESCUE_BIG), "s"(cptr) : "memory");
+    }
 
     // fragment read addresses: unit row (wave strip + lane&31), 16-byte chunk ((ks*2 + lh) ^ swz) = (q<<4) ^ (ks<<5)
     unsigned va[4], vb[4];
@@ -468,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     const int tiles_m = tiles_mn / a.tiles_n;
     const int band_tiles = tiles_m * a.band;
     auto tile_origin = [&](int i, int& m0, int& n0, int& ks) {
-        int tile = xcd_remap((int)blockIdx.x + i * G, a.ntiles);
+        int tile = xcd_remap(vblk + (i + ibase) * G, a.ntiles);
         ks = tile / tiles_mn;
         tile -= ks * tiles_mn;
         const int cb = tile / band_tiles, r = tile - cb * band_tiles;
@@ -569,7 +588,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         }
     }
 
+    constexpr int PFN = NtPf<EPI>::N;
+    u32x4 pf[8];          // epilogue operands fetched ahead by the main loop (epi_prefetch; unused when PFN == 0)
+    f32x16 acc[2][2][2];  // [A half][32-row sub-block][B half], each a 32x32 C^T tile
+    bf16x8 fa[2][2];      // A fragments: [buffer][sub-block]
+    bf16x8 fb[2][4];      // B fragments of the whole K-tile: [B half][k-substep]
+    const unsigned stg = lds_base + RING_BYTES + wave * STG_BYTES;
+    long long* dbg = nullptr;
+#ifdef OCN_DEV_BUILD
+    if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = g_nt5_trace + (blockIdx.x ? 512 : 0);
+#endif
+
+  for (int pass = 0;; ++pass) {  // one pass without RESCUE; with it: the own share, then one rescued entry per pass
+   if (!RESCUE || my_tiles > 0) {
     // ---- prologue: K-tiles 0 and 1 (minus A1(1)) ----
+    ab_i = a1_i = 0;
+    ab_k = a1_k = 0;
     set_ab(0);
     set_a1(0);
     DMA_A0(0, 0) DMA_A0(1, 0) DMA_B0(0, 0) DMA_B0(1, 0) DMA_B1(0, 0) DMA_B1(1, 0)
@@ -579,13 +613,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     DMA_A0(0, 1) DMA_A0(1, 1) DMA_B0(0, 1) DMA_B0(1, 1) DMA_B1(0, 1) DMA_B1(1, 1)
     adv_ab();
 
-    constexpr int PFN = NtPf<EPI>::N;
-    u32x4 pf[8];          // epilogue operands fetched ahead by the main loop (epi_prefetch; unused when PFN == 0)
-    f32x16 acc[2][2][2];  // [A half][32-row sub-block][B half], each a 32x32 C^T tile
-    bf16x8 fa[2][2];      // A fragments: [buffer][sub-block]
-    bf16x8 fb[2][4];      // B fragments of the whole K-tile: [B half][k-substep]
-
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RESCUE) if (fresh) {  // (the vmcnt(0) above has seen the claim return: the counter retires in issue order)
+        fresh = false;
+        asm volatile("" : "+v"(claim)::"memory");  // no copy of the claim is made before this point
+        if (threadIdx.x == 0) box[0] = claim;
+        __syncthreads();
+        const int lo = min(__builtin_amdgcn_readfirstlane(box[0]), my_tiles);
+        if (lo > 0) {  // finishers took the head of this share before the workgroup got a CU: start again behind them
+            ibase = lo;
+            my_tiles -= lo;
+            __syncthreads();
+            --pass;
+            continue;
+        }
+    }
     __builtin_amdgcn_s_barrier();
 
 // OCN_PRIO_MODE (compile-time experiment, profiles/r02_setprio_experiment.txt): 1 = s_setprio 1 around every MFMA group of the main loop,
@@ -684,11 +726,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         PRIO_OFF() SB(); LGKM0(); SB();                                                                      \
     }
 
-    const unsigned stg = lds_base + RING_BYTES + wave * STG_BYTES;
-    long long* dbg = nullptr;
-#ifdef OCN_DEV_BUILD
-    if (DBG && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 133)) dbg = g_nt5_trace + (blockIdx.x ? 512 : 0);
-#endif
 #define STAMP(IDX) if (DBG && dbg && i < 8) dbg[i * 8 + (IDX)] = wall_clock64();
 #if (OCN_PRIO_MODE & 2)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -726,6 +763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         if constexpr (PFN > 0) __builtin_amdgcn_s_barrier();  // publishes the next tile's first K-tile (see KTILE, PFM = 2)
         STAMP(4)
     }
+   }  // my_tiles > 0
     // ---- the launch's last round, in HALF tiles ---------------------------------------------------------------------------
     // ntiles is rarely a multiple of the grid: the N = 768 GEMMs of ViT-B-32 at batch 4096 have 2400 tiles for 256 CUs -- nine full rounds and
     // a tenth in which 96 workgroups compute a whole tile each while 160 CUs idle (6 % of the launch; 8.5 % for the text tower's N = 512
@@ -735,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
     // K-tile (16 MFMAs per wave: A x (B0, B1) with the B fragments read as they are used) and one barrier: the slot of K-tile g is free once
     // every wave has read its last fragments, which is where the barrier sits, and is refilled right behind it -- B two K-tiles ahead (it comes
     // from L2), A four K-tiles ahead through the two A units a half tile does not otherwise need (it comes from HBM).
-    if constexpr (EPI != OCN_EPI_CE_ONEPASS && EPI != OCN_EPI_CE_ONEPASS_FULL) if (a.tail_n > 0) {
+    if constexpr (EPI != OCN_EPI_CE_ONEPASS && EPI != OCN_EPI_CE_ONEPASS_FULL) if (a.tail_n > 0 && pass == 0) {
         int t = -1, h = 0;
         if ((int)blockIdx.x < a.tail_n) t = (int)blockIdx.x;
         else if ((int)blockIdx.x >= a.tail_partner && (int)blockIdx.x < a.tail_partner + a.tail_n) { t = (int)blockIdx.x - a.tail_partner; h = 1; }
@@ -820,6 +858,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt5_kernel(GemmNtArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetches must land before the LDS is released
+    if constexpr (!RESCUE) break;
+    else {
+        // ---- this workgroup is done with what it had: look for a share nobody has started -------------------------------------------------
+        bool got = false;
+        for (;;) {
+            __syncthreads();  // everybody is out of the ring and the staging areas (first round) / has read the mailbox (later rounds)
+            if (threadIdx.x == 0) box[1] = 0x7fffffff;
+            __syncthreads();
+            for (int t = threadIdx.x; t < G - 1; t += 512) {  // candidates in rotated order: the finishers spread over the victims
+                int w = (int)blockIdx.x + 1 + t;
+                w -= w >= G ? G : 0;
+                if (__hip_atomic_load(a.rescue + w * OCN_RESCUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < share_of(w)) atomicMin(box + 1, t);
+            }
+            __syncthreads();
+            const int t = box[1];
+            if (t == 0x7fffffff) break;  // every share has been started or handed out
+            int w = (int)blockIdx.x + 1 + t;
+            w -= w >= G ? G : 0;
+            if (threadIdx.x == 0) box[0] = atomicAdd(a.rescue + w * OCN_RESCUE_STRIDE, 1);
+            __syncthreads();
+            const int k = __builtin_amdgcn_readfirstlane(box[0]);
+            if (k < share_of(w)) {  // entry k of share w is this workgroup's (else: the owner started or another finisher was faster -- look again)
+                vblk = __builtin_amdgcn_readfirstlane(w);
+                ibase = k;
+                my_tiles = 1;
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
+        __syncthreads();  // the mailbox has been read: wave 0's staging area is the epilogue's again
+    }
+  }  // pass
 #undef KTILE
 #undef MM
 #undef RD_A
@@ -874,12 +945,24 @@ int nt5_stagger(int ntiles, int K, int forced) {
 }
 
 template <int EPI, int AUXV>
-int launch5_aux(const GemmNtArgs& a, int grid, hipStream_t st) {
+int launch5_aux(GemmNtArgs a, int grid, hipStream_t st) {
     static bool set_ = false;
     if (!set_) {
         (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, AUXV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#ifndef OCN_DEV_BUILD
+        (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<EPI, false, AUXV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#endif
         set_ = true;
     }
+#ifndef OCN_DEV_BUILD  // (the developer build's many cache-policy instantiations exist in the static form only)
+    a.rescue = grid > 1 ? ocn_rescue_board(st, grid) : nullptr;
+    if (a.rescue) {
+        hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, AUXV, true>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+        OCN_CHECK_LAUNCH("ocn_gemm_nt");
+        return OCN_OK;
+    }
+#endif
+    a.rescue = nullptr;
     hipLaunchKernelGGL((gemm_nt5_kernel<EPI, false, AUXV>), dim3(grid), dim3(512), LDS_BYTES, st, a);
     OCN_CHECK_LAUNCH("ocn_gemm_nt");
     return OCN_OK;

@@ -54,12 +54,30 @@ OCN_DEV bf16x8 cat(const Frag& f) {
                    "+v"((S).a[2].hi), "+v"((S).a[3].lo), "+v"((S).a[3].hi), "+v"((S).b[0].lo), "+v"((S).b[0].hi),          \
                    "+v"((S).b[1].lo), "+v"((S).b[1].hi))
 
-template <bool BIAS>
-__global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
+// RESCUE (ocn_set_tile_rescue, the multi-GPU form; protocol: gemm_nt5.hip): a workgroup's share is its M-chunk in a.pieces pieces of a.piece_rows rows.
+// The owner adds RESCUE_BIG to its counter when it starts and takes the chunk from the first piece no finisher has claimed to the end (one epilogue);
+// a finisher claims ONE piece of a chunk nobody has started and adds its partial tile with the same fp32 atomics.  The bias slices stay consistent:
+// step s of a chunk (counted from the chunk's first row) belongs to the workgroup with tk == s (mod tiles_k), whoever computes it.
+constexpr int RESCUE_BIG = 1 << 20;
+template <bool BIAS, bool RESCUE = false>
+__global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wid = xcd_remap(blockIdx.x, a.nwg);
+    int unit = xcd_remap(blockIdx.x, a_in.nwg);  // the (tile, M-split) unit this pass works on
+    int piece0 = 0;                              // RESCUE: its first piece
+    int* const box = (int*)(smem + LDS_BYTES);   // RESCUE: workgroup-wide mailbox behind the ring (the launch asks for 64 bytes more)
+    // the owner's claim is issued here and read behind the first prologue, whose operand fetches cover its latency (gemm_nt5.hip)
+    int claim = 0;
+    bool fresh = RESCUE;
+    if constexpr (RESCUE) if (threadIdx.x == 0) {
+        // inline asm: hipcc's own atomicAdd is consumed on the spot (its wave-reduction wrapper reads the result back at once)
+        const int* cptr = a_in.rescue + unit * OCN_RESCUE_STRIDE;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(claim) : "v"(0), "v"(RESCUE_BIG), "s"(cptr) : "memory");
+    }
+  for (int pass = 0;; ++pass) {  // one pass without RESCUE; with it: the own chunk, then one rescued piece per pass
+    GemmTnArgs a = a_in;
+    const int wid = unit;
     const int ntile = a.ntile_all;
     const int split = wid / ntile;
     int tile = wid % ntile;
@@ -73,10 +91,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
     }
     const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
-    const int m_begin = split * a.chunk;
-    const int m_end = min(a.M, m_begin + a.chunk);
-    const int rows = m_end - m_begin;
+    int m_begin = split * a.chunk;
+    int m_end = min(a.M, m_begin + a.chunk);
+    if constexpr (RESCUE) {
+        m_begin += piece0 * a.piece_rows;
+        if (pass > 0) m_end = min(m_end, m_begin + a.piece_rows);
+    }
+    const int rows = max(m_end - m_begin, 0);
     const int nk = (rows + 31) / 32;
+   if (!RESCUE || rows > 0) {
     const int wn = wave >> 2, wk = wave & 3;
     const unsigned lds_base = (unsigned)(size_t)(OCN_LDS char*)smem;
 
@@ -167,6 +190,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
     int bc = tk;  // steps until this workgroup's next bias step
+    if constexpr (RESCUE) {
+        bc = tk - (piece0 * (a.piece_rows >> 5)) % a.tiles_k;  // the pass starts at step piece0 * piece_rows / 32 of the chunk
+        bc += bc < 0 ? a.tiles_k : 0;
+    }
 
     // ---- prologue: stages 0, 1, 2 ------------------------------------------------------------------------------------------
     DMA_A(0, 0) DMA_A(1, 0) DMA_B(0, 0) DMA_B(1, 0)
@@ -179,6 +206,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
 #if (OCN_PRIO_MODE & 2)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
+    if constexpr (RESCUE) if (fresh) {
+        fresh = false;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim)::"memory");  // the claim (issued first) and, with it, the three stages
+        if (threadIdx.x == 0) box[0] = claim;
+        __syncthreads();
+        const int lo = min(__builtin_amdgcn_readfirstlane(box[0]), a_in.pieces);
+        if (lo > 0) {  // finishers took the head of this chunk before the workgroup got a CU: start again behind their pieces
+            piece0 = lo;
+            __syncthreads();
+            --pass;
+            continue;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
@@ -255,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
 
     // ---- epilogue: fp32 atomics (lanes of a half-wave hit 32 consecutive k = one 128-byte line) ---------------------------
     const int lr = lane & 31;
+    if constexpr (!RESCUE) {
     if (a.ablate & 1) return;
     if (a.ws) {
         // reproducible form (ocn_gemm_tn_accum_det): every split stores its tile to its own slab and tn5_reduce_kernel sums the slabs
@@ -285,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
         }
         return;
     }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int blk = (i + wk) & 3;
@@ -305,6 +347,41 @@ __global__ __launch_bounds__(512, 2) void gemm_tn5_kernel(GemmTnArgs a) {
             if (gn < a.N) unsafeAtomicAdd(a.dbias + gn, a.alpha * accb[r]);
         }
     }
+   }  // rows > 0
+    if constexpr (!RESCUE) break;
+    else {
+        // ---- done with what this workgroup had: look for a chunk nobody has started (gemm_nt5.hip has the protocol) ---------------------------
+        const int G = a_in.nwg;
+        bool got = false;
+        for (;;) {
+            __syncthreads();  // everybody is out of the ring (first round) / has read the mailbox (later rounds)
+            if (threadIdx.x == 0) box[1] = 0x7fffffff;
+            __syncthreads();
+            const int self = xcd_remap(blockIdx.x, G);
+            for (int t = threadIdx.x; t < G - 1; t += 512) {
+                int w = self + 1 + t;
+                w -= w >= G ? G : 0;
+                if (__hip_atomic_load(a_in.rescue + w * OCN_RESCUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a_in.pieces) atomicMin(box + 1, t);
+            }
+            __syncthreads();
+            const int t = box[1];
+            if (t == 0x7fffffff) break;
+            int w = self + 1 + t;
+            w -= w >= G ? G : 0;
+            if (threadIdx.x == 0) box[0] = atomicAdd(a_in.rescue + w * OCN_RESCUE_STRIDE, 1);
+            __syncthreads();
+            const int k = __builtin_amdgcn_readfirstlane(box[0]);
+            if (k < a_in.pieces) {
+                unit = __builtin_amdgcn_readfirstlane(w);
+                piece0 = k;
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
+        __syncthreads();  // the mailbox has been read: the ring is the DMA's again
+    }
+  }  // pass
 }
 
 // dW[n,k] += alpha * sum_s ws[s][n][k] (slabs summed in split order);  dbias[n] += alpha * sum_p bias_slabs[p][n]
@@ -344,6 +421,26 @@ int tn5_splits(int M, int N, int K, int num_cu, int over) {
 
 }  // namespace
 extern int g_ocn_tuning[16];
+
+// Static launch, or -- ocn_set_tile_rescue(1), atomic epilogue only -- the rescue form: every M-chunk in up to 8 pieces of whole 128-row step groups
+static void tn5_launch(GemmTnArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 64);
+        (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 64);
+        attr_set = true;
+    }
+    a.rescue = (a.ws || a.ablate || a.nwg < 2) ? nullptr : ocn_rescue_board(st, a.nwg);
+    a.piece_rows = ocn_cdiv(ocn_cdiv(a.chunk, 8), 128) * 128;
+    a.pieces = ocn_cdiv(a.chunk, a.piece_rows);
+    if (a.rescue) {
+        if (a.dbias) hipLaunchKernelGGL((gemm_tn5_kernel<true, true>), dim3(a.nwg), dim3(512), LDS_BYTES + 64, st, a);
+        else hipLaunchKernelGGL((gemm_tn5_kernel<false, true>), dim3(a.nwg), dim3(512), LDS_BYTES + 64, st, a);
+        return;
+    }
+    if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+}
 
 static int tn5_cus() {
     if (g_tn5_num_cu == 0) {
@@ -410,8 +507,7 @@ int ocn_launch_tn5(GemmTnArgs a, hipStream_t st) {
     a.ntile1 = a.ntile_all = ntile;  // single problem
     a.A2 = a.B2 = nullptr; a.dW2 = a.dbias2 = nullptr; a.lda2 = a.ldb2 = a.ldw2 = a.N2 = 0;
     if (a.ws && (a.ldw % 4 || a.K % 4 || g_ocn_tuning[11] > 1 || g_ocn_tuning[15] > 0)) return 1;  // (the scratch was sized for the default split)
-    if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
-    else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    tn5_launch(a, st);
     if (a.ws) {
         const long total4 = (long)a.N * a.K / 4;
         int grid = (int)((total4 + 255) / 256);
@@ -455,8 +551,7 @@ int ocn_launch_tn5_pair(GemmTnArgs a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_tn5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    if (a.dbias) hipLaunchKernelGGL(gemm_tn5_kernel<true>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
-    else hipLaunchKernelGGL(gemm_tn5_kernel<false>, dim3(a.nwg), dim3(512), LDS_BYTES, st, a);
+    tn5_launch(a, st);
     if (hipGetLastError() != hipSuccess) return OCN_ERR_LAUNCH;
     return OCN_OK;
 }

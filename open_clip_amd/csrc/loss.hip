@@ -278,7 +278,7 @@ extern "C" int ocn_fused_logits_ce(const void* X, int ldx, const void* Y, int ld
     GemmNtArgs a;
     a.A = (const bf16*)X; a.B = (const bf16*)Y; a.out = G; a.bias = nullptr; a.resid = nullptr; a.aux = nullptr;
     a.lda = ldx; a.ldb = ldy; a.ldc = ldg; a.M = R; a.N = N; a.K = E; a.alpha = 1.0f;
-    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0; a.ksplit = 1; a.ws_stride = 0;
+    a.tiles_n = 0; a.ntiles = 0; a.band = 0; a.stagger = 0; a.first_wave = 0; a.ablate = 0; a.ksplit = 1; a.ws_stride = 0; a.rescue = nullptr;
     const int parts = ocn_cdiv(N, 256) * 4;
     a.ce_parts = parts; a.ce_label_offset = label_offset; a.ce_grad_scale = grad_scale;
     a.ce_stats = workspace;

@@ -26,6 +26,8 @@ from contextlib import contextmanager
 
 import torch
 
+from . import ops
+
 _BLOCK = re.compile(r"^(.*resblocks\.\d+)\.")
 _HEAD = re.compile(r"^(visual\.(ln_post|proj|attn_pool)|ln_final|text_projection)\b")
 PACK_BELOW = 1 << 16  # elements: flat ranges smaller than this share one staging buffer and one collective per group
@@ -86,6 +88,7 @@ class NativeGradSync:
         overlap with the backward.  Without it (default) every registered parameter MUST receive a gradient in every synchronised backward:
         ``finish()`` raises otherwise, naming the parameters, instead of letting ranks issue different collectives (a silent RCCL hang)."""
         self.model, self.world_size, self.comm, self.pg = model, int(world_size), comm, process_group
+        ops.multi_gpu_defaults(self.world_size)  # the all-reduces' kernels hold CUs while the backward's GEMMs are launched: their rescue form
         self.find_unused = bool(find_unused_parameters)
         self.enabled = True
         self.stats = {"collectives": 0, "elements": 0, "ranges_per_group": [], "order": []}

@@ -333,6 +333,7 @@ class NativeClipLoss(nn.Module):
         self.comm = comm  # optional open_clip_amd.comm.NativeComm: the collectives through the C ABI instead of torch.distributed
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size = rank, world_size
+        ops.multi_gpu_defaults(world_size)
         # native extension (not a reference argument): evaluate the global loss (local_loss=False, gather_with_grad=False)
         # by rows per rank -- identical value and gradients, 1/W of the logits work, one extra reduce-scatter
         self.row_sharded = row_sharded
@@ -406,6 +407,7 @@ class NativeSigLipLoss(nn.Module):
         self.deterministic = bool(deterministic)  # as NativeClipLoss: the three sums in a fixed order instead of fp32 atomics
         self.comm = comm
         self.cache_labels, self.rank, self.world_size = cache_labels, rank, world_size
+        ops.multi_gpu_defaults(world_size)
         # loss.py:336-338: 'bidir' (default) / 'shift' / 'reduce' / 'gather' are four TRANSPORTS of the same sum -- every rank adds the negative-only loss
         # of its images against every other rank's text features.  The native form is the 'gather' one for all four (one all-gather forward, one
         # reduce-scatter backward: identical value and gradients, tests/test_dist_loss_gloo.py runs every name against the reference's vectors); the

@@ -66,6 +66,25 @@ def gemm_nt(epi, a, b, out, bias=None, resid=None, aux=None, alpha=1.0):
     return out
 
 
+def set_tile_rescue(on: bool):
+    """``ocn_set_tile_rescue``: the persistent GEMMs' multi-GPU form (finishing workgroups hand out the shares of workgroups whose CU is held by a
+    collective's kernel; include/openclip_hip.h).  Process-wide; same results (NT bit-identical, wgrad up to the order of its fp32 atomics)."""
+    _lib.call("ocn_set_tile_rescue", int(bool(on)))
+
+
+def tile_rescue() -> bool:
+    return bool(_lib.load().ocn_get_tile_rescue())
+
+
+def multi_gpu_defaults(world_size: int):
+    """What a data-parallel run switches on in the kernels (called by the distributed losses and by ``NativeGradSync`` when world_size > 1, i.e. wherever
+    collectives' kernels will hold CUs while GEMMs are launched): the GEMMs' rescue form.  ``set_tile_rescue(False)`` afterwards switches it off again;
+    the environment variable OCN_TILE_RESCUE=0 keeps it off."""
+    import os
+    if int(world_size) > 1 and torch.cuda.is_available() and os.environ.get("OCN_TILE_RESCUE", "1") != "0":
+        set_tile_rescue(True)
+
+
 def gemm_nt_splitk_plan(M, N, K):
     """K-slices ``gemm_nt_splitk`` should use for out[M,N] = a[M,K] @ b[N,K]^T (1: the product fills the chip as it is -- use ``gemm_nt``)"""
     return int(_lib.load().ocn_gemm_nt_splitk_plan(int(M), int(N), int(K)))

@@ -1,0 +1,254 @@
+"""The persistent GEMMs' multi-GPU form (``ocn_set_tile_rescue``, include/openclip_hip.h): workgroups that finish hand out the shares of
+workgroups that have not started.  What must hold: the NT GEMM's results are bit-identical to the static form's -- with and without CUs held by
+another stream's kernel (``ocn_debug_occupy`` parks workgroups that leave no room for a GEMM workgroup beside them, as a collective's kernels do);
+the wgrad sums the same products (fp32 atomics: order-dependent in the last bits, as between two static runs); every launch finds a zeroed board
+(a per-stream ring, re-zeroed when it wraps); and under contention the rescue form is what it is for: faster than the static one."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from open_clip_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _rescue_off_afterwards():
+    yield
+    ops.set_tile_rescue(False)
+
+
+_SIDE = []
+
+
+def _side():
+    """ONE side stream for the whole module (torch hands out pool streams round-robin and the runtime maps them onto a few hardware queues: a later
+    pool stream can share the default stream's queue, and an occupier queued there does not run beside the GEMM)"""
+    if not _SIDE:
+        _SIDE.append((torch.cuda.Stream(), torch.zeros(1, dtype=torch.int32, device=DEV)))
+    return _SIDE[0]
+
+
+def _occupy(n, micros, side, sink):
+    if n:
+        _lib.call("ocn_debug_occupy", n, micros, sink.data_ptr(), side.cuda_stream)
+        torch.cuda._sleep(60000)  # the occupier lands first (and is still there when the GEMM starts: the sleep is well under a millisecond)
+
+
+def _nt_cases():
+    g = torch.Generator(device=DEV).manual_seed(7)
+    out = []
+    for name, epi, M, N, K in [("plain", ops.EPI_BF16, 25600, 3072, 768), ("gelu", ops.EPI_BIAS_GELU, 25600, 3072, 768), ("dgelu", ops.EPI_DGELU, 25600, 3072, 768),
+                               ("resid32", ops.EPI_BIAS_RESID_F32, 25600, 768, 3072), ("resid16", ops.EPI_BIAS_RESID_BF16, 25600, 768, 3072),
+                               ("ragged", ops.EPI_BF16, 25000, 1000, 512), ("few tiles", ops.EPI_BF16, 2048, 1024, 512), ("f32", ops.EPI_F32, 12800, 512, 512)]:
+        a = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        b = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+        kw = {}
+        if epi in (ops.EPI_BIAS_GELU, ops.EPI_BIAS_RESID_F32, ops.EPI_BIAS_RESID_BF16):
+            kw["bias"] = torch.randn(N, device=DEV, generator=g)
+        if epi == ops.EPI_BIAS_RESID_F32:
+            kw["resid"] = torch.randn(M, N, device=DEV, generator=g)
+        if epi == ops.EPI_BIAS_RESID_BF16:
+            kw["resid"] = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        if epi == ops.EPI_BIAS_GELU:
+            kw["aux"] = torch.empty(M, N, device=DEV, dtype=torch.uint8)
+        if epi == ops.EPI_DGELU:
+            kw["aux"] = torch.randint(0, 256, (M, N), device=DEV, dtype=torch.uint8, generator=g)
+        odt = torch.float32 if epi in (ops.EPI_BIAS_RESID_F32, ops.EPI_F32) else torch.bfloat16
+        out.append((name, epi, a, b, odt, kw))
+    return out
+
+
+@pytest.mark.parametrize("held", [0, 3, 40])
+def test_nt_results_are_those_of_the_static_form(held):
+    side, sink = _side()
+    for name, epi, a, b, odt, kw in _nt_cases():
+        M, N = a.shape[0], b.shape[0]
+        ops.set_tile_rescue(False)
+        want = ops.gemm_nt(epi, a, b, torch.empty(M, N, device=DEV, dtype=odt), **kw)
+        want_aux = kw["aux"].clone() if epi == ops.EPI_BIAS_GELU else None
+        ops.set_tile_rescue(True)
+        assert ops.tile_rescue()
+        for rep in range(3):
+            if epi == ops.EPI_BIAS_GELU:
+                kw["aux"].zero_()
+            got = torch.full((M, N), float("nan"), device=DEV, dtype=odt)
+            torch.cuda.synchronize()
+            _occupy(held, 5000, side, sink)
+            ops.gemm_nt(epi, a, b, got, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"{name}, {held} CUs held, launch {rep}"
+            if want_aux is not None:
+                assert torch.equal(kw["aux"], want_aux), f"{name}: saved derivative"
+
+
+@pytest.mark.parametrize("held", [0, 3, 40])
+def test_wgrad_sums_the_same_products(held):
+    side, sink = _side()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for M, N, K, bias in [(51200, 3072, 768, True), (51200, 768, 3072, False), (20000, 520, 264, True), (4096 * 77 // 8, 512, 2048, True)]:
+        a = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        b = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        ref = a.double().t() @ b.double()
+        ref_b = a.double().sum(0)
+        ops.set_tile_rescue(False)
+        dw0, db0 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        ops.gemm_tn_accum(a, b, dw0, db0 if bias else None)
+        err0 = (dw0.double() - ref).abs().max().item()
+        ops.set_tile_rescue(True)
+        for rep in range(3):
+            dw, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            torch.cuda.synchronize()
+            _occupy(held, 5000, side, sink)
+            ops.gemm_tn_accum(a, b, dw, db if bias else None)
+            torch.cuda.synchronize()
+            err = (dw.double() - ref).abs().max().item()
+            assert err <= max(2.0 * err0, 1e-3 * M ** 0.5), f"[{M}x{N}x{K}] {held} held, launch {rep}: {err} vs static {err0}"
+            if bias:
+                assert (db.double() - ref_b).abs().max().item() <= 2e-3 * M ** 0.5
+                assert (db0.double() - ref_b).abs().max().item() <= 2e-3 * M ** 0.5
+
+
+def test_paired_wgrads_and_split_k_and_the_fused_loss_under_rescue():
+    side, sink = _side()
+    g = torch.Generator(device=DEV).manual_seed(13)
+    M, K = 51200, 768
+    a1, a2 = torch.randn(M, 768, device=DEV, generator=g).bfloat16(), torch.randn(M, 2304, device=DEV, generator=g).bfloat16()
+    b = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    r1, r2 = a1.double().t() @ b.double(), a2.double().t() @ b.double()
+    ops.set_tile_rescue(True)
+    for held in (0, 24):
+        w1, w2 = torch.zeros(768, K, device=DEV), torch.zeros(2304, K, device=DEV)
+        d1, d2 = torch.zeros(768, device=DEV), torch.zeros(2304, device=DEV)
+        torch.cuda.synchronize()
+        _occupy(held, 5000, side, sink)
+        ops.gemm_tn_accum2(a1, b, w1, d1, a2, b, w2, d2)
+        torch.cuda.synchronize()
+        assert (w1.double() - r1).abs().max().item() < 1e-3 * M ** 0.5 and (w2.double() - r2).abs().max().item() < 1e-3 * M ** 0.5
+        assert (d1.double() - a1.double().sum(0)).abs().max().item() < 2e-3 * M ** 0.5
+    # split-K NT (K-slices are entries of the same walk) and the one-pass cross-entropy epilogue: bit-identical to the static form
+    x = torch.randn(4096, 32768, device=DEV, generator=g).bfloat16()
+    y = (torch.randn(512, 32768, device=DEV, generator=g) * 0.01).bfloat16()
+    ks = ops.gemm_nt_splitk_plan(4096, 512, 32768)
+    fx = torch.nn.functional.normalize(torch.randn(4096, 512, device=DEV, generator=g), dim=-1).bfloat16()
+    fy = torch.nn.functional.normalize(torch.randn(8192, 512, device=DEV, generator=g), dim=-1).bfloat16()
+
+    def run():
+        o = ops.gemm_nt_splitk(x, y, torch.empty(4096, 512, device=DEV), ks) if ks > 1 else None
+        G = torch.empty(4096, 8192, device=DEV, dtype=torch.bfloat16)
+        acc = torch.zeros(2, device=DEV)
+        rowscale = ops.fused_logits_ce((fx.float() * 30.0).bfloat16(), fy, G, 8192, 0, 1.0 / 4096, 1.0 / 4096, acc[0:1], acc[1:2])
+        torch.cuda.synchronize()
+        return o, G, [rowscale, acc]
+
+    ops.set_tile_rescue(False)
+    o0, G0, res0 = run()
+    ops.set_tile_rescue(True)
+    for held in (0, 24):
+        torch.cuda.synchronize()
+        _occupy(held, 5000, side, sink)
+        o1, G1, res1 = run()
+        assert o0 is None or torch.equal(o0, o1)
+        assert torch.equal(G0, G1)
+        assert torch.equal(res0[0], res1[0])  # the row scales
+        torch.testing.assert_close(res0[1], res1[1], rtol=1e-5, atol=1e-6)  # loss / dscale sums: fp32 atomics over the rows
+
+
+def test_every_launch_finds_a_zeroed_board_across_ring_wraps():
+    """boards come from a ring of 512 per stream that is zeroed (stream-ordered) when it wraps: 1300 launches = two wraps, CUs held now and then"""
+    side, sink = _side()
+    g = torch.Generator(device=DEV).manual_seed(17)
+    a = torch.randn(8192, 256, device=DEV, generator=g).bfloat16()
+    b = torch.randn(1024, 256, device=DEV, generator=g).bfloat16()
+    ops.set_tile_rescue(False)
+    want = ops.gemm_nt(ops.EPI_BF16, a, b, torch.empty(8192, 1024, device=DEV, dtype=torch.bfloat16))
+    ops.set_tile_rescue(True)
+    outs = [torch.empty(8192, 1024, device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+    for i in range(1300):
+        if i % 100 == 50:
+            _occupy(20, 2000, side, sink)
+        ops.gemm_nt(ops.EPI_BF16, a, b, outs[i % 4])
+        if i % 4 == 3:
+            assert all(torch.equal(o, want) for o in outs), f"launch {i}"
+            for o in outs:
+                o.fill_(float("nan"))
+
+
+def test_rescue_is_faster_than_waiting_when_cus_are_held():
+    """the point of it: with CUs held for the whole launch the static form waits for a CU and then walks a whole share alone (up to 2x); the rescue
+    form spreads that share over the finishers.  Generous margins: the claim is the direction, the numbers are in profiles/"""
+    side, sink = _side()
+    M, N, K = 4096 * 50, 3072, 768
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    b = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+
+    def timed(held):
+        if held == 0:  # steady state: a row of launches
+            for _ in range(3):
+                ops.gemm_nt(ops.EPI_BF16, a, b, out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm_nt(ops.EPI_BF16, a, b, out)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 20
+        ts = []
+        for _ in range(5):  # one launch behind an occupier that holds its CUs for longer than the launch
+            torch.cuda.synchronize()
+            _occupy(max(held, 0), 6000, side, sink)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.gemm_nt(ops.EPI_BF16, a, b, out)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        print(f"  {held} held, rescue {ops.tile_rescue()}: " + " ".join(f"{t:.3f}" for t in ts))
+        return sorted(ts)[2]
+
+    ops.set_tile_rescue(False)
+    s_free, s_one, s_held = timed(0), timed(-1), timed(16)
+    ops.set_tile_rescue(True)
+    r_free, r_one, r_held = timed(0), timed(-1), timed(16)
+    print(f"static {s_free:.3f} / {s_one:.3f} / {s_held:.3f} ms, rescue {r_free:.3f} / {r_one:.3f} / {r_held:.3f} ms (steady / one launch / one launch with 16 CUs held)")
+    assert r_free <= 1.03 * s_free
+    assert s_held >= 1.3 * s_one  # the hazard exists
+    assert r_held <= 1.2 * s_one
+
+
+def test_training_step_under_rescue_with_cus_held_matches_the_static_step():
+    """the whole step (ViT-B-32, batch 256) with the rescue form on and 24 CUs held through it: features and loss bit-identical (every forward GEMM is
+    an NT launch), gradients the static step's up to the order of the wgrads' fp32 atomics (two static steps differ by as much)"""
+    from open_clip_amd.configs import get_model_config
+    from open_clip_amd.loss import NativeClipLoss
+    from open_clip_amd.model import NativeCLIP
+    from open_clip_amd.synth import init_state_dict, synthetic_batch
+    cfg = get_model_config("ViT-B-32")
+    state = init_state_dict(cfg, seed=3)
+    batch = synthetic_batch(cfg, 256, seed=5)
+    side, sink = _side()
+
+    def step(rescue, held):
+        ops.set_tile_rescue(rescue)
+        m = NativeCLIP(cfg["embed_dim"], cfg["vision_cfg"], cfg["text_cfg"], output_dict=True, image_stream="bf16")
+        m.load_state_dict(state, strict=True)
+        m = m.cuda().train()
+        torch.cuda.synchronize()
+        _occupy(held, 40000, side, sink)
+        out = m(image=batch["image"].cuda(), text=batch["text"].cuda())
+        loss = NativeClipLoss()(**out)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out["image_features"].float(), out["text_features"].float(), float(loss), {k: p.grad.float() for k, p in m.named_parameters()}
+
+    a = step(False, 0)
+    a2 = step(False, 0)
+    b = step(True, 24)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert abs(a[2] - b[2]) <= max(abs(a[2] - a2[2]), 2e-6 * abs(a[2]))  # the loss sums its rows with fp32 atomics
+    for k in a[3]:
+        noise = (a[3][k] - a2[3][k]).norm().item()
+        d = (a[3][k] - b[3][k]).norm().item()
+        assert d <= max(10.0 * noise, 1e-4 * a[3][k].norm().item()), f"{k}: {d:.3e} against run-to-run {noise:.3e}"

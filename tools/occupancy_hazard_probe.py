@@ -47,6 +47,9 @@ for name, M, N, K, epi in [("img fc", Mi, 3072, 768, 0), ("img fc gelu", Mi, 307
             row.append(f"{per_cu}/CU, {occ:2d} CUs held: {run(fn, occ):.3f} ms")
     _lib.call("ocn_set_tuning", 10, 0)
     print(f"NT {name}: " + " | ".join(row), flush=True)
+    ops.set_tile_rescue(True)  # the product's multi-GPU form: static shares, finishers hand out the shares of workgroups that have not started
+    print(f"NT {name}, tile rescue: " + " | ".join(f"{occ:2d} CUs held: {run(fn, occ):.3f} ms" for occ in (0, 1, 8, 32, 64)), flush=True)
+    ops.set_tile_rescue(False)
     del a, b, out, aux
 
 M, N, K = Mi, 3072, 768
@@ -67,3 +70,14 @@ for k in (1, 2, 3):
     torch.cuda.synchronize()
     print(f"wgrad img fc, {k} per CU: steady {e0.elapsed_time(e1) / 5:.3f} ms | " + " | ".join(f"{occ:2d} CUs held: {run(fn, occ):.3f} ms" for occ in (0, 1, 8, 32)), flush=True)
 _lib.call("ocn_set_tuning", 11, 0)
+ops.set_tile_rescue(True)
+fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+print(f"wgrad img fc, tile rescue: steady {e0.elapsed_time(e1) / 5:.3f} ms | " + " | ".join(f"{occ:2d} CUs held: {run(fn, occ):.3f} ms" for occ in (0, 1, 8, 32, 64)), flush=True)
+ops.set_tile_rescue(False)
