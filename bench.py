@@ -567,6 +567,8 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
         args.native_comm = args.native_allreduce = True
     tile_rescue = args.tile_rescue == "on" or (args.tile_rescue == "auto" and world > 1)
     from open_clip_amd import ops as _ops
+    if not tile_rescue:
+        os.environ["OCN_TILE_RESCUE"] = "0"  # (the distributed losses / NativeGradSync would switch it on for world_size > 1: ops.multi_gpu_defaults)
     _ops.set_tile_rescue(tile_rescue)
     # N > 1 over RCCL: the loss collectives go through the C ABI's communicator by default (north_star: "an RCCL all-gather ... through a thin C-ABI
     # extension"); --torch-comm keeps them on the process group, --native moves the gradient all-reduce there as well
