@@ -23,6 +23,12 @@ if has streams; then  # the three residual-stream modes of the image tower, alte
     timeout 300 python bench.py --steps 12 --warmup 3 --no-roofline $QUIET --image-stream $m 2>&1 | grep '^{' >> $O/${TAG}_streams_$m.json
   done; done; stamp streams
 fi
+if has rescue; then  # the GEMMs' rescue form: single launches with CUs held (static 1-3 workgroups per CU against rescue), then the step with the form off / on
+  timeout 600 python tools/occupancy_hazard_probe.py 2>&1 | grep -v "^/opt" > $O/${TAG}_occupancy_probe.txt
+  for i in 1 2 3; do for m in off on; do
+    timeout 300 python bench.py --steps 20 --warmup 5 $QUIET --no-roofline --tile-rescue $m 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$m', d['ms_per_step'], d['value'])" >> $O/${TAG}_rescue_ab.txt
+  done; done; stamp rescue
+fi
 if has cmd; then bash -c "$GPU_CMD" > $O/${TAG}_cmd.log 2>&1; stamp cmd; fi
 cd /tmp; export TMPDIR=/tmp
 if has prof; then  # every kernel alone on the chip (one stream, no wgrad side stream)
