@@ -219,8 +219,12 @@ def test_rescue_is_faster_than_waiting_when_cus_are_held():
 
 
 def test_training_step_under_rescue_with_cus_held_matches_the_static_step():
-    """the whole step (ViT-B-32, batch 256) with the rescue form on and 24 CUs held through it: features and loss bit-identical (every forward GEMM is
-    an NT launch), gradients the static step's up to the order of the wgrads' fp32 atomics (two static steps differ by as much)"""
+    """the whole step (ViT-B-32, batch 256) with the rescue form on and 24 CUs held through it: features bit-identical (every forward GEMM is an NT
+    launch), loss equal up to the order of its row sums.  Gradients: the order of ANY fp32 atomic sum upstream (the loss's dY product, the wgrads)
+    moves with timing -- with CUs held in the STATIC form just as well -- and a 1e-7 perturbation is amplified by every bf16 rounding behind it until
+    each element's rounding is effectively re-drawn: two runs of the same step differ by up to 2^-9 / sqrt(3) = 1.1e-3 rel-L2 per tensor (measured
+    3e-4 .. 9e-4 over static / rescue x free / held, tools/rescue_step_probe.py; ``deterministic=True`` is the mode without it).  A tile computed twice
+    or not at all would show at the percent level: the bound is 2.5e-3."""
     from open_clip_amd.configs import get_model_config
     from open_clip_amd.loss import NativeClipLoss
     from open_clip_amd.model import NativeCLIP
@@ -241,14 +245,12 @@ def test_training_step_under_rescue_with_cus_held_matches_the_static_step():
         loss = NativeClipLoss()(**out)
         loss.backward()
         torch.cuda.synchronize()
-        return out["image_features"].float(), out["text_features"].float(), float(loss), {k: p.grad.float() for k, p in m.named_parameters()}
+        return out["image_features"].detach().float(), out["text_features"].detach().float(), float(loss.detach()), {k: p.grad.float() for k, p in m.named_parameters()}
 
     a = step(False, 0)
-    a2 = step(False, 0)
-    b = step(True, 24)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert abs(a[2] - b[2]) <= max(abs(a[2] - a2[2]), 2e-6 * abs(a[2]))  # the loss sums its rows with fp32 atomics
-    for k in a[3]:
-        noise = (a[3][k] - a2[3][k]).norm().item()
-        d = (a[3][k] - b[3][k]).norm().item()
-        assert d <= max(10.0 * noise, 1e-4 * a[3][k].norm().item()), f"{k}: {d:.3e} against run-to-run {noise:.3e}"
+    for rescue, held in ((True, 0), (True, 24), (True, 24)):
+        b = step(rescue, held)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert abs(a[2] - b[2]) <= 4e-6 * abs(a[2])  # the loss sums its rows with fp32 atomics
+        worst = max((a[3][k] - b[3][k]).norm().item() / max(a[3][k].norm().item(), 1e-30) for k in a[3])
+        assert worst <= 2.5e-3, f"rescue {rescue}, {held} CUs held: worst gradient difference {worst:.2e} rel-L2"
