@@ -61,6 +61,9 @@ def main():
         for tot, n, rd, wr, us, k in rows:
             if k.startswith("gemm_"):
                 key = k.split("(")[0].replace(", ", ",")
+                # the static instantiations (last template argument RESCUE = false, round 6) keep the names bench.py has used since round 1
+                key = re.sub(r"^(gemm_nt5_kernel<\d+,false,\d+),false>$", r"\1>", key)
+                key = re.sub(r"^(gemm_tn5_kernel<(?:true|false)),false>$", r"\1>", key)
                 rec["by_kernel"][key] = {"launches": n, "read_bytes_per_launch": rd * 1e6, "write_bytes_per_launch": (wr if wr == wr else 0.0) * 1e6,
                                          "bytes_per_launch": (rd + (wr if wr == wr else 0.0)) * 1e6}
         json.dump(rec, open(sys.argv[3], "w"), indent=1)
