@@ -346,7 +346,8 @@ int ocn_comm_sendrecv(void* comm, const void* send, int to_rank, void* recv, int
  * ocn_set_tile_rescue(1) (process-wide, takes effect with the next launch) selects the kernels' rescue form: the shares stay static and no atomic enters
  * the tile loop, but workgroups that finish hand out -- entry by entry, through one counter per workgroup on a per-stream board -- the shares of workgroups
  * that have not started.  Results: ocn_gemm_nt bit-identical to the static form (every tile is computed once, by whichever workgroup), ocn_gemm_tn_accum
- * sums the same products with fp32 atomics in a different order, as between any two of its runs; the reproducible wgrad (workspace form) stays static.
+ * sums the same products with fp32 atomics in a different order, as between any two of its runs; the reproducible wgrad (workspace form) and launches
+ * recorded into a graph (stream capture) stay static.
  * Cost without contention: one atomic per workgroup at either end of a launch.  Off by default; open_clip_amd turns it on when world_size > 1. */
 int ocn_set_tile_rescue(int on);
 int ocn_get_tile_rescue(void);

@@ -39,9 +39,12 @@ extern "C" int ocn_get_tile_rescue(void) { return g_ocn_tile_rescue; }
 
 int* ocn_rescue_board(hipStream_t st, int workgroups) {
     // A ring of OCN_RESCUE_RING boards (2 MiB) per stream, one per launch, zeroed all at once (stream-ordered) every time the ring wraps: no launch has to clean
-    // up behind itself (a "last one out" counter costs 256 same-address atomics at the moment every workgroup finishes).  Not for graph capture: the
-    // ring position is host state.
+    // up behind itself (a "last one out" counter costs 256 same-address atomics at the moment every workgroup finishes).
     if (!g_ocn_tile_rescue || workgroups > OCN_RESCUE_SLOTS) return nullptr;
+    // a launch recorded into a graph would meet ITS board again at every replay, with the owners' marks of the first run still on it (every share would
+    // look taken): captured launches get the static form
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     struct Ring { int* base; unsigned next; };
     static std::mutex mu;
     static std::unordered_map<hipStream_t, Ring> rings;

@@ -254,3 +254,25 @@ def test_training_step_under_rescue_with_cus_held_matches_the_static_step():
         assert abs(a[2] - b[2]) <= 4e-6 * abs(a[2])  # the loss sums its rows with fp32 atomics
         worst = max((a[3][k] - b[3][k]).norm().item() / max(a[3][k].norm().item(), 1e-30) for k in a[3])
         assert worst <= 2.5e-3, f"rescue {rescue}, {held} CUs held: worst gradient difference {worst:.2e} rel-L2"
+
+
+def test_launches_captured_into_a_graph_take_the_static_form():
+    """a board is zeroed for ONE run of a launch; a graph replays the launch with the board as the first run left it (every share marked as started).
+    ``ocn_rescue_board`` therefore hands captured launches no board: replays compute everything"""
+    g = torch.Generator(device=DEV).manual_seed(19)
+    a = torch.randn(8192, 512, device=DEV, generator=g).bfloat16()
+    b = torch.randn(1024, 512, device=DEV, generator=g).bfloat16()
+    out = torch.empty(8192, 1024, device=DEV, dtype=torch.bfloat16)
+    ops.set_tile_rescue(False)
+    want = ops.gemm_nt(ops.EPI_BF16, a, b, torch.empty_like(out)).clone()
+    ops.set_tile_rescue(True)
+    ops.gemm_nt(ops.EPI_BF16, a, b, out)  # warm: attributes set, the stream's ring allocated
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.gemm_nt(ops.EPI_BF16, a, b, out)
+    for _ in range(3):
+        out.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
