@@ -47,13 +47,16 @@ int* ocn_rescue_board(hipStream_t st, int workgroups) {
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     struct Ring { int* base; unsigned next; };
     static std::mutex mu;
-    static std::unordered_map<hipStream_t, Ring> rings;
+    static std::unordered_map<uint64_t, Ring> rings;  // per (device, stream): the null stream has the same handle on every device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)st ^ ((uint64_t)(dev + 1) << 56);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = rings.find(st);
+    auto it = rings.find(key);
     if (it == rings.end()) {
         int* b = nullptr;
         if (hipMalloc((void**)&b, (size_t)OCN_RESCUE_RING * OCN_RESCUE_SLOTS * OCN_RESCUE_STRIDE * sizeof(int)) != hipSuccess) return nullptr;
-        it = rings.emplace(st, Ring{b, 0u}).first;
+        it = rings.emplace(key, Ring{b, 0u}).first;
     }
     Ring& r = it->second;
     const unsigned slot = r.next++ % OCN_RESCUE_RING;
