@@ -885,6 +885,8 @@ def run(args, rank, local_rank, world, dev, rank_devices, one_device):
                                 "algorithmic_tflop_per_launch_avg": round(dom["tflop"] / max(dom["launches"], 1), 4),
                                 "algorithmic_gb_per_launch_avg": round(dom["gbytes"] / max(dom["launches"], 1), 4),
                                 "dominant_by": "largest total time among the GEMM kernel instantiations inside the event-timed steps",
+                                "kernel_form": ("rescue (the instantiations carry a trailing `true`: gemm_tn5_kernel<.., true>, gemm_nt5_kernel<.., true>; the PMC traffic quoted "
+                                                "beside them was taken on the static form: same operand and result bytes)" if tile_rescue else "static"),
                                 "by_kernel": [krec(n, a) for n, a in sorted(s["by_kernel"].items(), key=lambda kv: -kv[1]["ms"])],
                                 "gemm_nt_family": {"achieved": round(nt["tflops"], 1), **roof(nt), "launches": nt["launches"],
                                                    "avg_launch_ms": round(nt["ms"] / max(nt["launches"], 1), 4)},
